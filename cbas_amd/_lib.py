@@ -1,0 +1,94 @@
+"""ctypes binding of libcbas_mi355x.so (declared in include/cbas_mi355x.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if that fails, or a
+call returns a non-zero code, a ``RuntimeError`` carrying ``cbas_last_error()`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
+
+
+class EncConfig(C.Structure):
+    _fields_ = [("hidden_size", c_int32), ("intermediate_size", c_int32), ("num_layers", c_int32),
+                ("num_heads", c_int32), ("num_register_tokens", c_int32), ("patch_size", c_int32),
+                ("layer_norm_eps", c_float), ("rope_theta", c_float), ("max_batch", c_int32),
+                ("max_height", c_int32), ("max_width", c_int32), ("precision", c_int32)]
+
+
+class HeadConfigC(C.Structure):
+    _fields_ = [("in_features", c_int32), ("out_features", c_int32), ("seq_len", c_int32),
+                ("bottleneck_dim", c_int32), ("lin0_dim", c_int32), ("lstm_hidden_size", c_int32),
+                ("center_window_size", c_int32), ("ema_alpha", c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/cbas_mi355x.h declares
+SIGNATURES = {
+    "cbas_enc_weights_count": (c_int64, [C.POINTER(EncConfig)]),
+    "cbas_enc_create": (c_int, [C.POINTER(EncConfig), c_void_p, c_int64, c_int, C.POINTER(c_void_p)]),
+    "cbas_enc_destroy": (None, [c_void_p]),
+    "cbas_enc_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cbas_enc_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                                    c_void_p, c_void_p, c_void_p]),
+    "cbas_enc_submit_u8_host": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64]),
+    "cbas_enc_wait": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                                          c_int, c_int]),
+    "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_head_weights_count": (c_int64, [C.POINTER(HeadConfigC)]),
+    "cbas_head_create": (c_int, [C.POINTER(HeadConfigC), c_void_p, c_int64, c_int, C.POINTER(c_void_p)]),
+    "cbas_head_destroy": (None, [c_void_p]),
+    "cbas_head_forward_windows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "cbas_head_infer_f16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
+    "cbas_last_error": (C.c_char_p, []),
+    "cbas_abi_version": (c_int, []),
+    "cbas_device_info": (c_int, [c_int, C.c_char_p, c_int, C.POINTER(c_int32), C.POINTER(c_int64)]),
+}
+
+ENC_SLOTS = 3
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if needed) the native library; raises if it cannot be had."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            if not build_if_missing:
+                raise RuntimeError(f"{path} is missing; run `python -m cbas_amd.build`")
+            _build.build_library()
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().cbas_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else '?'}")
+
+
+def device_info(device_id: int = 0):
+    lib = load()
+    buf = C.create_string_buffer(64)
+    ncu, hbm = c_int32(0), c_int64(0)
+    check(lib.cbas_device_info(device_id, buf, 64, C.byref(ncu), C.byref(hbm)), "cbas_device_info")
+    return buf.value.decode(), int(ncu.value), int(hbm.value)

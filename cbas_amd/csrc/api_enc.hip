@@ -1,0 +1,474 @@
+// C-ABI: encoder handle (DinoEncoder replacement).  See include/cbas_mi355x.h for the contract and
+// the reference lines each entry point stands in for.
+#include <math.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "api_common.h"
+#include "kernels.h"
+
+thread_local char g_cbas_err[512] = {0};
+
+extern "C" const char* cbas_last_error(void) { return g_cbas_err; }
+extern "C" int cbas_abi_version(void) { return CBAS_ABI_VERSION; }
+
+extern "C" int cbas_device_info(int device_id, char* arch_out, int arch_cap, int32_t* n_cu, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (arch_out && arch_cap > 0) {
+        strncpy(arch_out, prop.gcnArchName, arch_cap - 1);
+        arch_out[arch_cap - 1] = 0;
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return CBAS_OK;
+}
+
+namespace {
+
+struct LayerW {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *o_b, *ls1, *up_b, *down_b, *ls2;
+    float* qkv_b;                       // [3D] = q.b | 0 | v.b
+    f16 *wqkv, *wo, *wup, *wdown;       // fp16 (hi)
+    f16 *wqkv_lo, *wo_lo, *wup_lo, *wdown_lo;
+};
+
+struct Slot {
+    uint8_t* in_host = nullptr;   // pinned, green planes
+    uint8_t* in_dev = nullptr;
+    uint16_t* out16_host = nullptr;
+    float* out32_host = nullptr;
+    f16* out16_dev = nullptr;
+    float* out32_dev = nullptr;
+    hipEvent_t ev_copied = nullptr, ev_done = nullptr;
+    int n = 0;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct cbas_enc {
+    cbas_enc_config cfg;
+    int device;
+    int D, F, L, NH, R, NP;            // NP = prefix tokens
+    float* blob = nullptr;             // all fp32 parameters on device
+    std::vector<LayerW> layers;
+    const float *prefix, *patch_b, *norm_w, *norm_b;
+    f16 *w16 = nullptr, *w16_lo = nullptr;     // all fp16 weights (hi / lo)
+    f16 *wpatch, *wpatch2, *wpatch_lo, *wpatch2_lo;
+    float* qkv_bias_all = nullptr;
+    // rope tables for the last resolution
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_nh = 0, rope_nw = 0, rope_cap = 0;
+    // workspaces
+    int64_t rows_cap = 0, prow_cap = 0;
+    f16 *A_patch = nullptr, *h16 = nullptr, *qkv16 = nullptr, *u16 = nullptr;
+    float* x = nullptr;
+    int last_rows = 0;
+    hipStream_t compute = nullptr, copy = nullptr;
+    Slot slots[CBAS_ENC_SLOTS];
+    int64_t slot_pixels = 0;
+};
+
+namespace {
+
+int64_t weights_count(const cbas_enc_config& c) {
+    const int64_t D = c.hidden_size, F = c.intermediate_size, R = c.num_register_tokens, p = c.patch_size;
+    int64_t n = D + R * D + D * 3 * p * p + D;
+    const int64_t per = 2 * D + (D * D + D) + D * D + (D * D + D) + (D * D + D) + D + 2 * D + (F * D + F) + (D * F + D) + D;
+    n += per * c.num_layers;
+    n += 2 * D;
+    return n;
+}
+
+int ensure_rope(cbas_enc* h, int nh, int nw, hipStream_t stream) {
+    if (h->rope_nh == nh && h->rope_nw == nw) return CBAS_OK;
+    const int P = nh * nw;
+    if (P > h->rope_cap) return cbas_fail(CBAS_EINVAL, "frame has %d patches, workspace holds %d", P, h->rope_cap);
+    // [tf]:96-121 patch-centre coordinates, :153-200 angles; float32 throughout like the reference
+    std::vector<float> c((size_t)P * 64), s((size_t)P * 64);
+    float inv_freq[16];
+    for (int j = 0; j < 16; ++j) inv_freq[j] = 1.0f / powf(h->cfg.rope_theta, (float)j * (4.0f / 64.0f));
+    const float two_pi = 6.283185307179586f;
+    for (int iy = 0; iy < nh; ++iy)
+        for (int ix = 0; ix < nw; ++ix) {
+            const float cy = 2.0f * (((float)iy + 0.5f) / (float)nh) - 1.0f;
+            const float cx = 2.0f * (((float)ix + 0.5f) / (float)nw) - 1.0f;
+            float* cr = &c[(size_t)(iy * nw + ix) * 64];
+            float* sr = &s[(size_t)(iy * nw + ix) * 64];
+            for (int d = 0; d < 32; ++d) {
+                const float coord = d < 16 ? cy : cx;
+                const float ang = (two_pi * coord) * inv_freq[d & 15];
+                cr[d] = cr[d + 32] = cosf(ang);
+                sr[d] = sr[d + 32] = sinf(ang);
+            }
+        }
+    // synchronous copies (first use of a resolution only); the source vectors die at return
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(h->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    h->rope_nh = nh;
+    h->rope_nw = nw;
+    return CBAS_OK;
+}
+
+int check_frame(cbas_enc* h, int n, int height, int width) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    if (n <= 0 || n > h->cfg.max_batch) return cbas_fail(CBAS_EINVAL, "n=%d outside (0, max_batch=%d]", n, h->cfg.max_batch);
+    if (height < 16 || width < 16) return cbas_fail(CBAS_EINVAL, "frame %dx%d smaller than one patch", height, width);
+    const int64_t P = (int64_t)(height / 16) * (width / 16);
+    if ((int64_t)n * (P + h->NP) > h->rows_cap || (int64_t)n * P > h->prow_cap)
+        return cbas_fail(CBAS_EINVAL, "%d frames of %dx%d exceed the workspace (max_batch=%d, %dx%d)", n, height,
+                         width, h->cfg.max_batch, h->cfg.max_height, h->cfg.max_width);
+    return CBAS_OK;
+}
+
+// Everything after ingest: patch GEMM, L transformer blocks, final CLS norm.
+int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_scale, float* cls_f32,
+               f16* cls_f16, hipStream_t st, int stop_layer, int stop_stage) {
+    const int nh = height / 16, nw = width / 16, P = nh * nw, T = P + h->NP;
+    const int D = h->D, F = h->F;
+    const int M = n * T, M_pad = (int)round_up(M, 128);
+    h->last_rows = M;
+    int rc = ensure_rope(h, nh, nw, st);
+    if (rc) return rc;
+
+    GemmParams g{};
+    g.A = h->A_patch;
+    g.W = patch_k == 256 ? h->wpatch : h->wpatch2;
+    g.W_lo = h->cfg.precision ? (patch_k == 256 ? h->wpatch_lo : h->wpatch2_lo) : nullptr;
+    g.M = n * P; g.M_pad = (int)round_up(n * P, 128); g.N = D; g.K = patch_k;
+    g.bias = h->patch_b; g.out_f32 = h->x; g.ldo = D;
+    g.patches_per_frame = P; g.tokens_per_frame = T; g.n_prefix = h->NP; g.in_scale = in_scale;
+    LAUNCH_TRY(launch_gemm(EPI_PATCH, g, st));
+    if (stop_layer == 0 && stop_stage == 0) return CBAS_OK;
+
+    for (int l = 0; l < h->L; ++l) {
+        const LayerW& w = h->layers[l];
+        auto stop = [&](int stage) { return stop_layer == l && stop_stage == stage; };
+        LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st));
+        if (stop(1)) return CBAS_OK;
+
+        GemmParams q{};
+        q.A = h->h16; q.W = w.wqkv; q.W_lo = h->cfg.precision ? w.wqkv_lo : nullptr;
+        q.M = M; q.M_pad = M_pad; q.N = 3 * D; q.K = D; q.bias = w.qkv_b; q.out_f16 = h->qkv16; q.ldo = 3 * D;
+        q.tokens_per_frame = T; q.n_prefix = h->NP; q.rope_cos = h->rope_cos; q.rope_sin = h->rope_sin; q.D = D;
+        LAUNCH_TRY(launch_gemm(EPI_QKV, q, st));
+        if (stop(2)) return CBAS_OK;
+
+        LAUNCH_TRY(launch_attention(h->qkv16, h->h16, n, T, D, h->NH, st));
+        if (stop(3)) return CBAS_OK;
+
+        GemmParams o{};
+        o.A = h->h16; o.W = w.wo; o.W_lo = h->cfg.precision ? w.wo_lo : nullptr;
+        o.M = M; o.M_pad = M_pad; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out_f32 = h->x; o.ldo = D;
+        LAUNCH_TRY(launch_gemm(EPI_RESID, o, st));
+        if (stop(4)) return CBAS_OK;
+
+        LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st));
+        if (stop(5)) return CBAS_OK;
+
+        GemmParams u{};
+        u.A = h->h16; u.W = w.wup; u.W_lo = h->cfg.precision ? w.wup_lo : nullptr;
+        u.M = M; u.M_pad = M_pad; u.N = F; u.K = D; u.bias = w.up_b; u.out_f16 = h->u16; u.ldo = F;
+        LAUNCH_TRY(launch_gemm(EPI_GELU, u, st));
+        if (stop(6)) return CBAS_OK;
+
+        GemmParams d{};
+        d.A = h->u16; d.W = w.wdown; d.W_lo = h->cfg.precision ? w.wdown_lo : nullptr;
+        d.M = M; d.M_pad = M_pad; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out_f32 = h->x; d.ldo = D;
+        LAUNCH_TRY(launch_gemm(EPI_RESID, d, st));
+        if (stop(7)) return CBAS_OK;
+    }
+    if (cls_f32 || cls_f16)
+        LAUNCH_TRY(launch_final_norm_cls(h->x, h->norm_w, h->norm_b, cls_f32, cls_f16, n, T, D,
+                                         h->cfg.layer_norm_eps, st));
+    return CBAS_OK;
+}
+
+int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
+               int64_t row_stride, int64_t pixel_stride, float* cls_f32, f16* cls_f16, hipStream_t st,
+               int stop_layer, int stop_stage) {
+    int rc = check_frame(h, n, height, width);
+    if (rc) return rc;
+    if (!frames_dev) return cbas_fail(CBAS_EINVAL, "frames_dev is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    const int T = (height / 16) * (width / 16) + h->NP;
+    LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
+                                h->x, h->prefix, h->NP, h->D, T, st));
+    return run_blocks(h, n, height, width, 256, 1.0f / 255.0f, cls_f32, cls_f16, st, stop_layer, stop_stage);
+}
+
+}  // namespace
+
+extern "C" int64_t cbas_enc_weights_count(const cbas_enc_config* cfg) { return cfg ? weights_count(*cfg) : -1; }
+
+extern "C" void cbas_enc_destroy(cbas_enc* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->compute) (void)hipStreamSynchronize(h->compute);
+    if (h->copy) (void)hipStreamSynchronize(h->copy);
+    for (Slot& s : h->slots) {
+        if (s.in_host) (void)hipHostFree(s.in_host);
+        if (s.out16_host) (void)hipHostFree(s.out16_host);
+        if (s.out32_host) (void)hipHostFree(s.out32_host);
+        if (s.in_dev) (void)hipFree(s.in_dev);
+        if (s.out16_dev) (void)hipFree(s.out16_dev);
+        if (s.out32_dev) (void)hipFree(s.out32_dev);
+        if (s.ev_copied) (void)hipEventDestroy(s.ev_copied);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    }
+    void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->rope_cos, h->rope_sin,
+                    h->A_patch, h->h16, h->qkv16, h->u16, h->x};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->compute) (void)hipStreamDestroy(h->compute);
+    if (h->copy) (void)hipStreamDestroy(h->copy);
+    delete h;
+}
+
+extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_host, int64_t n_weights,
+                               int device_id, cbas_enc** out) {
+    if (!cfg || !weights_host || !out) return cbas_fail(CBAS_EINVAL, "null argument");
+    *out = nullptr;
+    const cbas_enc_config& c = *cfg;
+    if (c.hidden_size <= 0 || c.hidden_size % 128 || c.num_heads * 64 != c.hidden_size)
+        return cbas_fail(CBAS_EINVAL, "hidden_size=%d must be a multiple of 128 with head_dim 64 (num_heads=%d)",
+                         c.hidden_size, c.num_heads);
+    if (c.intermediate_size <= 0 || c.intermediate_size % 128)
+        return cbas_fail(CBAS_EINVAL, "intermediate_size=%d must be a multiple of 128", c.intermediate_size);
+    if (c.hidden_size > 1024) return cbas_fail(CBAS_EINVAL, "hidden_size > 1024 not supported");
+    if (c.patch_size != 16) return cbas_fail(CBAS_EINVAL, "patch_size must be 16");
+    if (c.num_layers <= 0 || c.num_register_tokens < 0 || c.max_batch <= 0 || c.max_height < 16 || c.max_width < 16)
+        return cbas_fail(CBAS_EINVAL, "bad layer/register/batch/frame-size field");
+    if (n_weights != weights_count(c))
+        return cbas_fail(CBAS_EINVAL, "weights blob has %lld floats, config needs %lld", (long long)n_weights,
+                         (long long)weights_count(c));
+    HIP_TRY(hipSetDevice(device_id));
+
+    cbas_enc* h = new (std::nothrow) cbas_enc();
+    if (!h) return cbas_fail(CBAS_ENOMEM, "out of host memory");
+    h->cfg = c; h->device = device_id;
+    h->D = c.hidden_size; h->F = c.intermediate_size; h->L = c.num_layers; h->NH = c.num_heads;
+    h->R = c.num_register_tokens; h->NP = 1 + h->R;
+    const int64_t D = h->D, F = h->F;
+
+#define CREATE_TRY(expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            cbas_fail(CBAS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            cbas_enc_destroy(h);                                                                          \
+            return _e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP;                                   \
+        }                                                                                                 \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&h->blob, n_weights * sizeof(float)));
+    CREATE_TRY(hipMemcpy(h->blob, weights_host, n_weights * sizeof(float), hipMemcpyHostToDevice));
+
+    // fp16 weight arena: patch (D*256 + D*512) + per layer (3DD + DD + FD + DF)
+    const int64_t n16 = D * 256 + D * 512 + (int64_t)h->L * (4 * D * D + 2 * F * D);
+    CREATE_TRY(hipMalloc(&h->w16, n16 * sizeof(f16)));
+    if (c.precision) CREATE_TRY(hipMalloc(&h->w16_lo, n16 * sizeof(f16)));
+    CREATE_TRY(hipMalloc(&h->qkv_bias_all, (int64_t)h->L * 3 * D * sizeof(float)));
+    CREATE_TRY(hipMemset(h->qkv_bias_all, 0, (int64_t)h->L * 3 * D * sizeof(float)));
+
+    hipStream_t st = h->compute;
+    const float* p = h->blob;
+    f16* w = h->w16;
+    f16* wl = h->w16_lo;
+    auto lo = [&](f16* hi_ptr) -> f16* { return wl ? wl + (hi_ptr - h->w16) : nullptr; };
+
+    h->prefix = p; p += (1 + h->R) * D;                 // cls_token | register_tokens: rows of the prefix
+    const float* patch_w = p; p += D * 768;
+    h->patch_b = p; p += D;
+    h->wpatch = w; w += D * 256;
+    h->wpatch2 = w; w += D * 512;
+    h->wpatch_lo = lo(h->wpatch); h->wpatch2_lo = lo(h->wpatch2);
+    int rc = launch_pack_patch_weight(patch_w, h->wpatch, h->wpatch_lo, h->wpatch2, h->wpatch2_lo, (int)D, st);
+
+    h->layers.resize(h->L);
+    for (int l = 0; l < h->L && !rc; ++l) {
+        LayerW& lw = h->layers[l];
+        lw.qkv_b = h->qkv_bias_all + (int64_t)l * 3 * D;
+        lw.ln1_w = p; p += D;
+        lw.ln1_b = p; p += D;
+        const float* qw = p; p += D * D;
+        const float* qb = p; p += D;
+        const float* kw = p; p += D * D;
+        const float* vw = p; p += D * D;
+        const float* vb = p; p += D;
+        const float* ow = p; p += D * D;
+        lw.o_b = p; p += D;
+        lw.ls1 = p; p += D;
+        lw.ln2_w = p; p += D;
+        lw.ln2_b = p; p += D;
+        const float* uw = p; p += F * D;
+        lw.up_b = p; p += F;
+        const float* dw = p; p += D * F;
+        lw.down_b = p; p += D;
+        lw.ls2 = p; p += D;
+        lw.wqkv = w; w += 3 * D * D;
+        lw.wo = w; w += D * D;
+        lw.wup = w; w += F * D;
+        lw.wdown = w; w += D * F;
+        lw.wqkv_lo = lo(lw.wqkv); lw.wo_lo = lo(lw.wo); lw.wup_lo = lo(lw.wup); lw.wdown_lo = lo(lw.wdown);
+        rc |= launch_convert_f16(qw, lw.wqkv, lw.wqkv_lo, D * D, st);
+        rc |= launch_convert_f16(kw, lw.wqkv + D * D, lw.wqkv_lo ? lw.wqkv_lo + D * D : nullptr, D * D, st);
+        rc |= launch_convert_f16(vw, lw.wqkv + 2 * D * D, lw.wqkv_lo ? lw.wqkv_lo + 2 * D * D : nullptr, D * D, st);
+        rc |= launch_convert_f16(ow, lw.wo, lw.wo_lo, D * D, st);
+        rc |= launch_convert_f16(uw, lw.wup, lw.wup_lo, F * D, st);
+        rc |= launch_convert_f16(dw, lw.wdown, lw.wdown_lo, D * F, st);
+        CREATE_TRY(hipMemcpyAsync(lw.qkv_b, qb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CREATE_TRY(hipMemcpyAsync(lw.qkv_b + 2 * D, vb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    h->norm_w = p; p += D;
+    h->norm_b = p; p += D;
+    if (rc || (p - h->blob) != n_weights) {
+        cbas_fail(CBAS_EHIP, "weight packing failed (rc=%d, consumed %lld of %lld)", rc, (long long)(p - h->blob),
+                  (long long)n_weights);
+        cbas_enc_destroy(h);
+        return CBAS_EHIP;
+    }
+
+    // workspaces
+    const int64_t Pmax = (int64_t)(c.max_height / 16) * (c.max_width / 16);
+    const int64_t Tmax = Pmax + h->NP;
+    h->rows_cap = round_up((int64_t)c.max_batch * Tmax, 128);
+    h->prow_cap = round_up((int64_t)c.max_batch * Pmax, 128);
+    h->rope_cap = (int)Pmax;
+    CREATE_TRY(hipMalloc(&h->rope_cos, Pmax * 64 * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->rope_sin, Pmax * 64 * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->A_patch, h->prow_cap * 512 * sizeof(f16)));
+    CREATE_TRY(hipMalloc(&h->x, h->rows_cap * D * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->h16, h->rows_cap * D * sizeof(f16)));
+    CREATE_TRY(hipMalloc(&h->qkv16, h->rows_cap * 3 * D * sizeof(f16)));
+    CREATE_TRY(hipMalloc(&h->u16, h->rows_cap * F * sizeof(f16)));
+    CREATE_TRY(hipMemsetAsync(h->A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
+    CREATE_TRY(hipMemsetAsync(h->x, 0, h->rows_cap * D * sizeof(float), st));
+    CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * sizeof(f16), st));
+    CREATE_TRY(hipMemsetAsync(h->qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
+    CREATE_TRY(hipMemsetAsync(h->u16, 0, h->rows_cap * F * sizeof(f16), st));
+
+    // host-streaming slots
+    h->slot_pixels = (int64_t)c.max_batch * c.max_height * c.max_width;
+    for (Slot& s : h->slots) {
+        CREATE_TRY(hipHostMalloc(&s.in_host, h->slot_pixels, hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc(&s.out16_host, (int64_t)c.max_batch * D * 2, hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc(&s.out32_host, (int64_t)c.max_batch * D * 4, hipHostMallocDefault));
+        CREATE_TRY(hipMalloc(&s.in_dev, h->slot_pixels));
+        CREATE_TRY(hipMalloc(&s.out16_dev, (int64_t)c.max_batch * D * 2));
+        CREATE_TRY(hipMalloc(&s.out32_dev, (int64_t)c.max_batch * D * 4));
+        CREATE_TRY(hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    }
+    CREATE_TRY(hipStreamSynchronize(st));
+#undef CREATE_TRY
+    *out = h;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
+                                   int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                                   float* cls_f32_dev, uint16_t* cls_f16_dev, void* stream) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    hipStream_t st = (hipStream_t)stream;
+    return forward_u8(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32_dev,
+                      (f16*)cls_f16_dev, st, -1, -1);
+}
+
+extern "C" int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int height, int width,
+                                    float* cls_f32_dev, uint16_t* cls_f16_dev, void* stream) {
+    int rc = check_frame(h, n, height, width);
+    if (rc) return rc;
+    if (!x_dev) return cbas_fail(CBAS_EINVAL, "x_dev is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (height / 16) * (width / 16) + h->NP;
+    LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, st));
+    return run_blocks(h, n, height, width, 512, 1.0f, cls_f32_dev, (f16*)cls_f16_dev, st, -1, -1);
+}
+
+extern "C" int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
+                                         int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                                         int stop_layer, int stop_stage) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    int rc = forward_u8(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, nullptr, nullptr,
+                        h->compute, stop_layer, stop_stage);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes) {
+    if (!h || !host_out) return cbas_fail(CBAS_EINVAL, "null argument");
+    const void* src = nullptr;
+    int64_t cap = 0;
+    switch (which) {
+        case 0: src = h->x; cap = h->rows_cap * h->D * 4; break;
+        case 1: src = h->h16; cap = h->rows_cap * h->D * 2; break;
+        case 2: src = h->qkv16; cap = h->rows_cap * 3 * h->D * 2; break;
+        case 3: src = h->u16; cap = h->rows_cap * h->F * 2; break;
+        default: return cbas_fail(CBAS_EINVAL, "unknown buffer %d", which);
+    }
+    if (n_bytes < 0 || n_bytes > cap) return cbas_fail(CBAS_EINVAL, "read of %lld bytes exceeds buffer (%lld)", (long long)n_bytes, (long long)cap);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    HIP_TRY(hipMemcpy(host_out, src, n_bytes, hipMemcpyDeviceToHost));
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
+                                       int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride) {
+    int rc = check_frame(h, n, height, width);
+    if (rc) return rc;
+    if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
+    if (!frames_host) return cbas_fail(CBAS_EINVAL, "frames_host is NULL");
+    Slot& s = h->slots[slot];
+    if (s.busy) return cbas_fail(CBAS_ESTATE, "slot %d is busy; call cbas_enc_wait first", slot);
+    const int64_t plane = (int64_t)height * width;
+    if ((int64_t)n * plane > h->slot_pixels) return cbas_fail(CBAS_EINVAL, "chunk exceeds slot staging size");
+    HIP_TRY(hipSetDevice(h->device));
+    // gather the consumed channel into the pinned staging buffer (packed green planes)
+    for (int f = 0; f < n; ++f) {
+        const uint8_t* src = frames_host + (int64_t)f * frame_stride;
+        uint8_t* dst = s.in_host + (int64_t)f * plane;
+        if (pixel_stride == 1 && row_stride == width) {
+            memcpy(dst, src, plane);
+        } else {
+            for (int y = 0; y < height; ++y) {
+                const uint8_t* r = src + (int64_t)y * row_stride;
+                uint8_t* d = dst + (int64_t)y * width;
+                if (pixel_stride == 1) memcpy(d, r, width);
+                else for (int xx = 0; xx < width; ++xx) d[xx] = r[(int64_t)xx * pixel_stride];
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(s.in_dev, s.in_host, (int64_t)n * plane, hipMemcpyHostToDevice, h->copy));
+    HIP_TRY(hipEventRecord(s.ev_copied, h->copy));
+    HIP_TRY(hipStreamWaitEvent(h->compute, s.ev_copied, 0));
+    rc = forward_u8(h, s.in_dev, n, height, width, plane, width, 1, s.out32_dev, s.out16_dev, h->compute, -1, -1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(s.out16_host, s.out16_dev, (int64_t)n * h->D * 2, hipMemcpyDeviceToHost, h->compute));
+    HIP_TRY(hipMemcpyAsync(s.out32_host, s.out32_dev, (int64_t)n * h->D * 4, hipMemcpyDeviceToHost, h->compute));
+    HIP_TRY(hipEventRecord(s.ev_done, h->compute));
+    s.n = n;
+    s.busy = true;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, float* cls_f32_host) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
+    Slot& s = h->slots[slot];
+    if (!s.busy) return cbas_fail(CBAS_ESTATE, "slot %d has no submitted work", slot);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(s.ev_done));
+    if (cls_f16_host) memcpy(cls_f16_host, s.out16_host, (int64_t)s.n * h->D * 2);
+    if (cls_f32_host) memcpy(cls_f32_host, s.out32_host, (int64_t)s.n * h->D * 4);
+    s.busy = false;
+    return CBAS_OK;
+}

@@ -1,0 +1,395 @@
+// ViT kernels other than the GEMM: frame ingest (im2col of the green plane), LayerNorm, fused
+// multi-head attention, final CLS LayerNorm, weight packing.  gfx950 only.
+//
+// Reference arithmetic replaced:
+//   ingest        backend/cbas.py:431 (green/255), :674 (gray -> 3 identical channels, folded into
+//                 the patch weights by pack_patch_weight), [tf]:82-83 (Conv2d k=s=16 as im2col), :86-89 (prefix tokens)
+//   layernorm     [tf]:404,410 (norm1/norm2), :540 (final norm; only the CLS row is needed, cbas.py:677)
+//   attention     [tf]:210-234 (softmax(q k^T * 64^-0.5) v), heads split/merge :311-313,:330
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// ingest
+// ---------------------------------------------------------------------------------------------
+// One thread = one 16-pixel patch row.  A[m][i*16 + j], m = b*P + py*nw + px.
+__global__ void im2col_u8_kernel(const uint8_t* __restrict__ frames, int n, int height, int width,
+                                 int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                                 f16* __restrict__ A, int nh, int nw) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n * nh * 16 * nw;
+    if (gid >= total) return;
+    const int px = gid % nw;
+    const int64_t t1 = gid / nw;
+    const int y = t1 % (nh * 16);
+    const int b = t1 / (nh * 16);
+    const int py = y >> 4, i = y & 15;
+    const uint8_t* src = frames + b * frame_stride + (int64_t)y * row_stride + (int64_t)px * 16 * pixel_stride;
+    f16x8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = (f16)(float)src[j * pixel_stride];
+        hi[j] = (f16)(float)src[(j + 8) * pixel_stride];
+    }
+    f16* dst = A + ((int64_t)b * nh * nw + (int64_t)py * nw + px) * 256 + i * 16;
+    *reinterpret_cast<f16x8*>(dst) = lo;
+    *reinterpret_cast<f16x8*>(dst + 8) = hi;
+}
+
+// float input: K = 512, columns [0,256) hold fp16(x), [256,512) hold fp16(x - fp16(x)).
+__global__ void im2col_f32_kernel(const float* __restrict__ frames, int n, int height, int width,
+                                  f16* __restrict__ A, int nh, int nw) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n * nh * 16 * nw;
+    if (gid >= total) return;
+    const int px = gid % nw;
+    const int64_t t1 = gid / nw;
+    const int y = t1 % (nh * 16);
+    const int b = t1 / (nh * 16);
+    const int py = y >> 4, i = y & 15;
+    const float* src = frames + ((int64_t)b * height + y) * width + px * 16;
+    f16* dst = A + ((int64_t)b * nh * nw + (int64_t)py * nw + px) * 512 + i * 16;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = src[half * 8 + j];
+            const f16 hv = (f16)v;
+            h[j] = hv;
+            l[j] = (f16)(v - (float)hv);
+        }
+        *reinterpret_cast<f16x8*>(dst + half * 8) = h;
+        *reinterpret_cast<f16x8*>(dst + 256 + half * 8) = l;
+    }
+}
+
+__global__ void write_prefix_kernel(float* __restrict__ x, const float* __restrict__ prefix, int n,
+                                    int n_prefix, int D, int T) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)n_prefix * (D / 4);
+    if (gid >= (int64_t)n * per) return;
+    const int b = gid / per;
+    const int rem = gid - (int64_t)b * per;
+    const int r = rem / (D / 4), c = rem - r * (D / 4);
+    reinterpret_cast<f32x4*>(x + ((int64_t)b * T + r) * D)[c] = reinterpret_cast<const f32x4*>(prefix + (int64_t)r * D)[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, two-pass statistics in registers (matches the reference's
+// mean / biased-variance formulation), fp32 in, fp16 out.
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, int D, float eps, int lane,
+                                       f32x4 (&y)[NV]) {
+    const int nvec = D >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        v[k] = (idx < nvec) ? reinterpret_cast<const f32x4*>(xr)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            const f32x4 d = v[k] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[idx];
+            const f32x4 bb = reinterpret_cast<const f32x4*>(beta)[idx];
+            y[k] = (v[k] - mean) * rstd * g + bb;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, f16* __restrict__ out,
+                                                            int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 y[NV];
+    ln_row<NV>(x + (size_t)row * D, gamma, beta, D, eps, lane, y);
+    const int nvec = D >> 2;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            f16x4 h = {(f16)y[k][0], (f16)y[k][1], (f16)y[k][2], (f16)y[k][3]};
+            reinterpret_cast<f16x4*>(out + (size_t)row * D)[idx] = h;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void final_norm_cls_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ cls_f32,
+                                                             f16* __restrict__ cls_f16, int n, int T, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    f32x4 y[NV];
+    ln_row<NV>(x + (size_t)b * T * D, gamma, beta, D, eps, lane, y);
+    const int nvec = D >> 2;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            if (cls_f32) reinterpret_cast<f32x4*>(cls_f32 + (size_t)b * D)[idx] = y[k];
+            if (cls_f16) {
+                f16x4 h = {(f16)y[k][0], (f16)y[k][1], (f16)y[k][2], (f16)y[k][3]};   // round-to-nearest-even, as h5py's f4->f2 cast
+                reinterpret_cast<f16x4*>(cls_f16 + (size_t)b * D)[idx] = h;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention: one workgroup per (frame, head).  K and V of the head (T x 64 fp16 each) live in LDS;
+// each wave takes 16-query tiles.  S^T = K Q^T is computed with the key on the MFMA row so that a
+// lane holds, for ONE query, 4 keys per key tile: the softmax reductions are in-lane plus two
+// cross-lane steps, and the probabilities are already laid out as the B operand of the P.V MFMA.
+// V is read through ds_read_b64_tr_b16 (hardware transpose) as the A operand, giving O^T with 4
+// consecutive head dims per lane (one 8-byte store per tile).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_off(int row, int col) {   // col in halves
+    return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
+                                                        int T, int D, int n_heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NKT * 16;
+    char* Ks = smem;
+    char* Vs = smem + ROWS * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / n_heads, hd = blockIdx.x - b * n_heads;
+    const size_t ld = (size_t)3 * D;
+    const f16* qbase = qkv + (size_t)b * T * ld + hd * 64;
+    const f16* kbase = qbase + D;
+    const f16* vbase = qbase + 2 * D;
+
+    for (int idx = tid; idx < ROWS * 8; idx += blockDim.x) {
+        const int r = idx >> 3, c = idx & 7;
+        f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < T) {
+            kv = *reinterpret_cast<const f16x8*>(kbase + (size_t)r * ld + c * 8);
+            vv = *reinterpret_cast<const f16x8*>(vbase + (size_t)r * ld + c * 8);
+        }
+        *reinterpret_cast<f16x8*>(Ks + k_off(r, c)) = kv;
+        *reinterpret_cast<f16x8*>(Vs + v_off(r, c * 8)) = vv;
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, li = lane & 15;
+    const int nqt = (T + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += nwaves) {
+        const int q = qt * 16 + li;
+        const int qrow = q < T ? q : T - 1;
+        f16x8 qf[2];
+        qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
+        qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
+
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + k_off(kt * 16 + li, dd * 4 + g));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dd], s[kt], 0, 0, 0);
+            }
+        }
+        // s[kt][r] = S[q][key = kt*16 + 4g + r]   (q already carries the 1/8 scale)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                const float v = key < T ? s[kt][r] : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f((s[kt][r] - mx) * 1.4426950408889634f);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < NKT / 2; ++s2) {
+            const f32x4 p0 = s[2 * s2], p1 = s[2 * s2 + 1];
+            const f16x8 pf = {(f16)p0[0], (f16)p0[1], (f16)p0[2], (f16)p0[3],
+                              (f16)p1[0], (f16)p1[1], (f16)p1[2], (f16)p1[3]};
+            const int krow = 32 * s2 + 4 * g + (li >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = 16 * dt + 4 * (li & 3);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow, col)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow + 16, col)));
+                union { struct { s16x4 a, b; } s; f16x8 v; } u;
+                u.s.a = lo; u.s.b = hi;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < T) {
+            const float inv = 1.0f / sum;
+            f16* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 w = o[dt] * inv;
+                f16x4 hv = {(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
+                *reinterpret_cast<f16x4*>(orow + 16 * dt) = hv;
+            }
+        }
+    }
+}
+
+template <int NKT>
+int launch_attention_t(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
+    constexpr int lds = NKT * 16 * 128 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<NKT>), dim3(n * n_heads), dim3(256), lds, stream, qkv, out, T, D, n_heads);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (runs once at create)
+// ---------------------------------------------------------------------------------------------
+__global__ void convert_f16_kernel(const float* __restrict__ src, f16* __restrict__ hi, f16* __restrict__ lo, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i];
+    const f16 h = (f16)v;
+    hi[i] = h;
+    if (lo) lo[i] = (f16)(v - (float)h);
+}
+
+// hi/lo: (D,256); hi2/lo2: (D,512) = [W' | W'] for the float-input path (fp16(x) | residual share W')
+__global__ void pack_patch_weight_kernel(const float* __restrict__ w, f16* __restrict__ hi, f16* __restrict__ lo,
+                                         f16* __restrict__ hi2, f16* __restrict__ lo2, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over D*256
+    if (i >= D * 256) return;
+    const int d = i >> 8, k = i & 255;
+    const float* base = w + (size_t)d * 768 + k;
+    const float v = (base[0] + base[256]) + base[512];       // sum over the 3 identical input channels
+    const f16 h = (f16)v;
+    const f16 l = (f16)(v - (float)h);
+    hi[i] = h;
+    hi2[d * 512 + k] = h;
+    hi2[d * 512 + 256 + k] = h;
+    if (lo) { lo[i] = l; lo2[d * 512 + k] = l; lo2[d * 512 + 256 + k] = l; }
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+int launch_im2col_u8(const uint8_t* frames, int n, int height, int width, int64_t frame_stride,
+                     int64_t row_stride, int64_t pixel_stride, f16* A, float* x, const float* prefix_tokens,
+                     int n_prefix, int D, int T, hipStream_t stream) {
+    const int nh = height / 16, nw = width / 16;
+    const int64_t total = (int64_t)n * nh * 16 * nw;
+    hipLaunchKernelGGL(im2col_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
+                       height, width, frame_stride, row_stride, pixel_stride, A, nh, nw);
+    const int64_t tp = (int64_t)n * n_prefix * (D / 4);
+    hipLaunchKernelGGL(write_prefix_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens,
+                       n, n_prefix, D, T);
+    return CHECK_LAUNCH();
+}
+
+int launch_im2col_f32(const float* frames, int n, int height, int width, f16* A, float* x,
+                      const float* prefix_tokens, int n_prefix, int D, int T, hipStream_t stream) {
+    const int nh = height / 16, nw = width / 16;
+    const int64_t total = (int64_t)n * nh * 16 * nw;
+    hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
+                       height, width, A, nh, nw);
+    const int64_t tp = (int64_t)n * n_prefix * (D / 4);
+    hipLaunchKernelGGL(write_prefix_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens,
+                       n, n_prefix, D, T);
+    return CHECK_LAUNCH();
+}
+
+int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, f16* out, int M, int D,
+                         float eps, hipStream_t stream) {
+    const int nv = (D / 4 + 63) / 64;
+    const dim3 grid((M + 3) / 4), block(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layernorm_f16_kernel<1>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_f16_kernel<2>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_f16_kernel<3>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
+        case 4: hipLaunchKernelGGL(layernorm_f16_kernel<4>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
+        default: return -1;
+    }
+    return CHECK_LAUNCH();
+}
+
+int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
+                          f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream) {
+    const int nv = (D / 4 + 63) / 64;
+    const dim3 grid((n + 3) / 4), block(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(final_norm_cls_kernel<1>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
+        case 2: hipLaunchKernelGGL(final_norm_cls_kernel<2>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
+        case 3: hipLaunchKernelGGL(final_norm_cls_kernel<3>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
+        case 4: hipLaunchKernelGGL(final_norm_cls_kernel<4>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
+        default: return -1;
+    }
+    return CHECK_LAUNCH();
+}
+
+int launch_attention(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
+    const int nkt = (T + 15) / 16;
+    if (nkt <= 2) return launch_attention_t<2>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 6) return launch_attention_t<6>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 14) return launch_attention_t<14>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 18) return launch_attention_t<18>(qkv, out, n, T, D, n_heads, stream);
+    return -1;   // T > 288: needs the streaming (online-softmax) variant, not built yet
+}
+
+int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(convert_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, hi, lo, n);
+    return CHECK_LAUNCH();
+}
+
+int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_patch_weight_kernel, dim3((D * 256 + 255) / 256), dim3(256), 0, stream, w, hi, lo, hi2, lo2, D);
+    return CHECK_LAUNCH();
+}

@@ -1,0 +1,196 @@
+"""``DinoEncoder`` — drop-in for the reference's encoder object (backend/cbas.py:650-677).
+
+Same constructor (``DinoEncoder(model_identifier: str, device="cuda")``), same ``.device``
+attribute, same call contract (``encoder(x)`` with ``x`` float32 ``(B, S, H, W)`` in [0, 1] ->
+``(B, S, D)``), but the forward pass runs in the hand-written HIP kernels of libcbas_mi355x.so
+through the C ABI (``cbas_enc_*``).  torch tensors are only containers for device memory.
+
+Extras beyond the reference interface (used by ``encode_file`` and the benchmarks):
+``encode_u8`` takes uint8 frames already in HBM, ``submit_host``/``wait`` stream host chunks
+through pinned staging with copy/compute overlap.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ViTConfig, find_checkpoint_dir
+from .weights import load_encoder_checkpoint
+
+
+def pack_encoder_weights(cfg: ViTConfig, w: Dict[str, np.ndarray]) -> np.ndarray:
+    """Flatten an HF state dict into the blob order documented in include/cbas_mi355x.h."""
+    D = cfg.hidden_size
+    parts = [w["embeddings.cls_token"].reshape(-1), w["embeddings.register_tokens"].reshape(-1),
+             w["embeddings.patch_embeddings.weight"].reshape(-1), w["embeddings.patch_embeddings.bias"].reshape(-1)]
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layer.{i}."
+        for k in ("norm1.weight", "norm1.bias", "attention.q_proj.weight", "attention.q_proj.bias",
+                  "attention.k_proj.weight", "attention.v_proj.weight", "attention.v_proj.bias",
+                  "attention.o_proj.weight", "attention.o_proj.bias", "layer_scale1.lambda1",
+                  "norm2.weight", "norm2.bias", "mlp.up_proj.weight", "mlp.up_proj.bias",
+                  "mlp.down_proj.weight", "mlp.down_proj.bias", "layer_scale2.lambda1"):
+            parts.append(np.asarray(w[p + k], np.float32).reshape(-1))
+    parts += [w["norm.weight"].reshape(-1), w["norm.bias"].reshape(-1)]
+    blob = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32) for p in parts]))
+    assert blob.shape[0] > D
+    return blob
+
+
+def _device_index(device: torch.device) -> int:
+    if device.type != "cuda":
+        raise RuntimeError(
+            f"cbas_amd runs only on an AMD GPU exposed as torch device 'cuda' (got {device}); there is no CPU path")
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+class DinoEncoder:
+    """MI355X DINOv3 ViT encoder behind the reference's ``DinoEncoder`` interface."""
+
+    def __init__(self, model_identifier: str, device="cuda", max_batch: int = 64,
+                 max_frame: Tuple[int, int] = (256, 256), precision: int = 0):
+        ckpt = find_checkpoint_dir(model_identifier)
+        cfg, weights = load_encoder_checkpoint(ckpt)
+        self._init(cfg, weights, device, max_batch, max_frame, precision)
+        self.model_identifier = model_identifier
+
+    @classmethod
+    def from_weights(cls, cfg: ViTConfig, weights: Dict[str, np.ndarray], device="cuda", max_batch: int = 64,
+                     max_frame: Tuple[int, int] = (256, 256), precision: int = 0) -> "DinoEncoder":
+        self = cls.__new__(cls)
+        self._init(cfg, weights, device, max_batch, max_frame, precision)
+        self.model_identifier = "<in-memory>"
+        return self
+
+    def _init(self, cfg: ViTConfig, weights, device, max_batch, max_frame, precision):
+        cfg.validate()
+        self.config = cfg
+        self.device = torch.device(device)
+        self._dev = _device_index(self.device)
+        self.max_batch = int(max_batch)
+        self.max_frame = (int(max_frame[0]), int(max_frame[1]))
+        self._lib = _lib.load()
+        self._cfg_c = _lib.EncConfig(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers,
+                                     cfg.num_attention_heads, cfg.num_register_tokens, cfg.patch_size,
+                                     cfg.layer_norm_eps, cfg.rope_theta, self.max_batch, self.max_frame[0],
+                                     self.max_frame[1], int(precision))
+        blob = pack_encoder_weights(cfg, weights)
+        need = self._lib.cbas_enc_weights_count(C.byref(self._cfg_c))
+        if need != blob.shape[0]:
+            raise RuntimeError(f"weight blob has {blob.shape[0]} floats, library expects {need}")
+        h = C.c_void_p()
+        _lib.check(self._lib.cbas_enc_create(C.byref(self._cfg_c), blob.ctypes.data, blob.shape[0], self._dev,
+                                             C.byref(h)), "cbas_enc_create")
+        self._h = h
+
+    # -- nn.Module-like surface used by the reference ------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device and torch.device(device).type != self.device.type:
+            raise RuntimeError("the MI355X encoder cannot be moved off its device")
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cbas_enc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the reference call: encoder(x) ---------------------------------------------------------
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """backend/cbas.py:672-677: x (B,S,H,W) float32 in [0,1] -> (B,S,D) float32."""
+        B, S, H, W = x.shape
+        x = x.to(self.device, dtype=torch.float32).contiguous().reshape(B * S, H, W)
+        out = torch.empty((B * S, self.config.hidden_size), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for i in range(0, B * S, self.max_batch):
+            n = min(self.max_batch, B * S - i)
+            _lib.check(self._lib.cbas_enc_forward_f32(self._h, x[i:i + n].data_ptr(), n, H, W,
+                                                      out[i:i + n].data_ptr(), None, stream),
+                       "cbas_enc_forward_f32")
+        return out.reshape(B, S, self.config.hidden_size)
+
+    # -- uint8 fast paths -------------------------------------------------------------------------
+    def encode_u8(self, frames: torch.Tensor, channel: int = 1, want_f32: bool = True):
+        """frames: uint8 device tensor (n,H,W,3) [decord layout; ``channel`` selects green] or (n,H,W).
+        Returns (cls_f16 (n,D) torch.float16, cls_f32 (n,D) or None)."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda
+        frames = frames.contiguous()
+        if frames.dim() == 4:
+            n, H, W, Cn = frames.shape
+            strides = (H * W * Cn, W * Cn, Cn)
+            base_off = channel
+        else:
+            n, H, W = frames.shape
+            strides = (H * W, W, 1)
+            base_off = 0
+        D = self.config.hidden_size
+        out16 = torch.empty((n, D), dtype=torch.float16, device=self.device)
+        out32 = torch.empty((n, D), dtype=torch.float32, device=self.device) if want_f32 else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for i in range(0, n, self.max_batch):
+            m = min(self.max_batch, n - i)
+            _lib.check(self._lib.cbas_enc_forward_u8(
+                self._h, frames[i:i + m].data_ptr() + base_off, m, H, W, strides[0], strides[1], strides[2],
+                out32[i:i + m].data_ptr() if want_f32 else None, out16[i:i + m].data_ptr(), stream),
+                "cbas_enc_forward_u8")
+        return out16, out32
+
+    def submit_host(self, slot: int, frames: np.ndarray, channel: int = 1) -> None:
+        """Queue one host chunk (uint8 (n,H,W,3) or (n,H,W), C-contiguous) on ``slot``."""
+        assert frames.dtype == np.uint8 and frames.flags.c_contiguous
+        if frames.ndim == 4:
+            n, H, W, Cn = frames.shape
+            strides, off = (H * W * Cn, W * Cn, Cn), channel
+        else:
+            n, H, W = frames.shape
+            strides, off = (H * W, W, 1), 0
+        _lib.check(self._lib.cbas_enc_submit_u8_host(self._h, slot, frames.ctypes.data + off, n, H, W, *strides),
+                   "cbas_enc_submit_u8_host")
+        self._slot_n = getattr(self, "_slot_n", {})
+        self._slot_n[slot] = n
+
+    def wait(self, slot: int, want_f32: bool = False):
+        n = self._slot_n[slot]
+        D = self.config.hidden_size
+        o16 = np.empty((n, D), np.float16)
+        o32 = np.empty((n, D), np.float32) if want_f32 else None
+        _lib.check(self._lib.cbas_enc_wait(self._h, slot, o16.ctypes.data, o32.ctypes.data if want_f32 else None),
+                   "cbas_enc_wait")
+        return o16, o32
+
+    # -- bring-up taps -----------------------------------------------------------------------------
+    def debug_tap(self, frames: torch.Tensor, stop_layer: int, stop_stage: int, which: int, channel: int = 1):
+        n, H, W = frames.shape[:3]
+        if frames.dim() == 4:
+            Cn = frames.shape[3]
+            strides, off = (H * W * Cn, W * Cn, Cn), channel
+        else:
+            strides, off = (H * W, W, 1), 0
+        torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.cbas_enc_debug_forward_u8(self._h, frames.data_ptr() + off, n, H, W, *strides,
+                                                       stop_layer, stop_stage), "cbas_enc_debug_forward_u8")
+        T = self.config.num_tokens(H, W)
+        D, F = self.config.hidden_size, self.config.intermediate_size
+        shape, dt = {0: ((n * T, D), np.float32), 1: ((n * T, D), np.float16), 2: ((n * T, 3 * D), np.float16),
+                     3: ((n * T, F), np.float16)}[which]
+        out = np.empty(shape, dt)
+        _lib.check(self._lib.cbas_enc_debug_read(self._h, which, out.ctypes.data, out.nbytes), "cbas_enc_debug_read")
+        return out

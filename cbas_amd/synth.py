@@ -1,0 +1,59 @@
+"""Synthetic inputs (frames and CLS sequences) shared by the golden-vector script, the tests and
+``bench.py``.  Everything derives from the counter-based hash in ``weights.py`` so the same bytes
+are produced on any machine; there is no dataset access in the build environment.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .weights import _hash_stream, synth_normal
+
+
+def noise_frames(seed: int, n: int, height: int, width: int, first: int = 0) -> np.ndarray:
+    """Uniform uint8 RGB noise, (n, H, W, 3); frame ``first + i`` is independent of ``n``."""
+    per = height * width * 3
+    words = (per + 7) // 8
+    out = np.empty((n, per), np.uint8)
+    for i in range(n):
+        h = _hash_stream(seed, f"noise_frame_{first + i}", words)
+        out[i] = h.view(np.uint8)[:per]
+    return out.reshape(n, height, width, 3)
+
+
+def cage_frames(seed: int, n: int, height: int, width: int, first: int = 0) -> np.ndarray:
+    """Structured clip: textured background, a bright blob that wanders (and sometimes rests) and
+    per-pixel sensor noise.  Gives CLS embeddings with temporal structure so the head's delta
+    streams and its argmax labels vary over the clip.  (n, H, W, 3) uint8; channel 1 is the one the
+    reference consumes (backend/cbas.py:431), channels 0/2 carry decoys."""
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    bg = 96.0 + 36.0 * np.sin(xx / 17.0) + 28.0 * np.cos(yy / 23.0) + 12.0 * np.sin((xx + yy) / 5.0)
+    out = np.empty((n, height, width, 3), np.uint8)
+    for i in range(n):
+        f = first + i
+        phase = f / 37.0
+        rest = 0.5 * (1.0 + np.tanh(4.0 * np.sin(f / 53.0)))          # 0 = resting, 1 = moving
+        cx = width * (0.5 + 0.35 * np.sin(2.1 * phase * rest + 0.3 * np.sin(f / 11.0)))
+        cy = height * (0.5 + 0.35 * np.cos(1.3 * phase * rest + 0.2 * np.cos(f / 7.0)))
+        sig = 0.09 * min(height, width) * (1.0 + 0.3 * np.sin(f / 19.0))
+        blob = 110.0 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2.0 * sig * sig))
+        nz = _hash_stream(seed, f"cage_noise_{f}", (height * width + 7) // 8).view(np.uint8)[:height * width]
+        g = bg + blob + (nz.reshape(height, width).astype(np.float64) - 127.5) * (18.0 / 127.5)
+        g8 = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+        out[i, :, :, 1] = g8
+        out[i, :, :, 0] = np.roll(g8, 7, axis=1)
+        out[i, :, :, 2] = 255 - g8
+    return out
+
+
+def cls_walk(seed: int, n: int, dim: int) -> np.ndarray:
+    """A float16 CLS-like sequence (n, dim) with temporal structure: slow random walk + jitter."""
+    steps = synth_normal(seed, "cls_walk_steps", (n, dim), 0.15).astype(np.float64)
+    base = synth_normal(seed, "cls_walk_base", (dim,), 1.0).astype(np.float64)
+    jitter = synth_normal(seed, "cls_walk_jitter", (n, dim), 0.05).astype(np.float64)
+    # leaky walk keeps the scale bounded for long clips
+    walk = np.empty((n, dim), np.float64)
+    acc = np.zeros(dim, np.float64)
+    for i in range(n):
+        acc = 0.97 * acc + steps[i]
+        walk[i] = acc
+    return (base + walk + jitter).astype(np.float16)

@@ -1,0 +1,172 @@
+/*
+ * cbas_mi355x.h — C ABI of libcbas_mi355x.so, the MI355X (gfx950) implementation of the one hot
+ * path of jones-lab-tamu/CBAS: streamed DINOv3-ViT frame encoding + sliding-window BiLSTM
+ * classification.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to the CBAS tree; "[tf]" =
+ * transformers/models/dinov3_vit/modeling_dinov3_vit.py, the third-party file that holds the
+ * encoder arithmetic the reference calls through AutoModel):
+ *
+ *   cbas_enc_create / cbas_enc_destroy     backend/cbas.py:651-670   DinoEncoder.__init__
+ *                                          (AutoModel.from_pretrained(...).to(device), eval, freeze)
+ *   cbas_enc_forward_f32                   backend/cbas.py:672-677   DinoEncoder.forward
+ *                                          + [tf]:523-548 DINOv3ViTModel.forward (CLS row only)
+ *   cbas_enc_forward_u8                    backend/cbas.py:431-436   green/255 preprocessing + encoder call
+ *   cbas_enc_submit_u8_host / cbas_enc_wait  backend/cbas.py:423-440 one iteration of the chunk loop
+ *                                          (H2D copy, encode, D2H copy), made asynchronous
+ *   cbas_head_create / cbas_head_destroy   backend/workthreads.py:427-447 ClassifierLSTMDeltas(...)
+ *                                          + load_state_dict + .to(device).eval()
+ *   cbas_head_forward_windows              backend/classifier_head.py:150-172 ClassifierLSTMDeltas.forward
+ *   cbas_head_infer_f16                    backend/cbas.py:497-551   the window loop of infer_file
+ *                                          (edge replicate padding, head, softmax(logits/max(1e-3,T)))
+ *   cbas_last_error                        Python exceptions raised on those paths
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative CBAS_E* code; no exception crosses the ABI.
+ *     cbas_last_error() returns a thread-local, NUL-terminated description of the last failure.
+ *   - "dev" pointers are HIP device pointers valid on the handle's device; "host" pointers are host
+ *     memory owned by the caller.  The library owns its weights, workspaces, streams and pinned
+ *     staging buffers; weights are copied during *_create.
+ *   - `stream` is a hipStream_t passed as void* (NULL = HIP's null stream, as in the HIP API).  All
+ *     *_forward_* / *_infer_* calls are asynchronous on that stream; the host-streamed
+ *     submit/wait pair uses the handle's own copy and compute streams.
+ *   - Handles are independent: distinct handles may be driven from distinct OS threads
+ *     concurrently (the reference runs EncodeThread and ClassificationThread side by side,
+ *     backend/workthreads.py:1256-1267).  One handle must not be used from two threads at once.
+ */
+#ifndef CBAS_MI355X_H
+#define CBAS_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBAS_OK            0
+#define CBAS_EINVAL       -1   /* bad argument / unsupported configuration */
+#define CBAS_EHIP         -2   /* a HIP runtime call failed */
+#define CBAS_ENOMEM       -3
+#define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
+
+#define CBAS_ABI_VERSION   1
+
+typedef struct cbas_enc  cbas_enc;
+typedef struct cbas_head cbas_head;
+
+/* ---- encoder ------------------------------------------------------------------------------ */
+
+/* Mirrors the HF config.json fields of a DINOv3 ViT ([tf] configuration_dinov3_vit.py:74-101). */
+typedef struct cbas_enc_config {
+    int32_t hidden_size;          /* D: 384 / 768 / 1024                       */
+    int32_t intermediate_size;    /* F: 4*D                                    */
+    int32_t num_layers;           /* L                                         */
+    int32_t num_heads;            /* D / 64 (head_dim must be 64)              */
+    int32_t num_register_tokens;  /* R (4 for the released checkpoints)        */
+    int32_t patch_size;           /* 16                                        */
+    float   layer_norm_eps;       /* 1e-5                                      */
+    float   rope_theta;           /* 100                                       */
+    int32_t max_batch;            /* frames per encoder pass (workspace size)  */
+    int32_t max_height;           /* largest frame the workspace must hold     */
+    int32_t max_width;
+    int32_t precision;            /* 0: fp16 operands, fp32 accumulate/residual (default)
+                                     1: fp16 hi+lo split weights (2 MFMA/k-step) */
+} cbas_enc_config;
+
+/* Number of float32 elements cbas_enc_create expects in `weights`, in this order:
+ *   cls_token[D], register_tokens[R*D], patch_weight[D*3*16*16], patch_bias[D],
+ *   then per layer: norm1.w[D] norm1.b[D] q.w[D*D] q.b[D] k.w[D*D] v.w[D*D] v.b[D] o.w[D*D] o.b[D]
+ *                   ls1[D] norm2.w[D] norm2.b[D] up.w[F*D] up.b[F] down.w[D*F] down.b[D] ls2[D],
+ *   then norm.w[D] norm.b[D].
+ * Linear weights are (out_features, in_features) row-major, exactly the HF state_dict tensors. */
+int64_t cbas_enc_weights_count(const cbas_enc_config* cfg);
+
+int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_host, int64_t n_weights,
+                    int device_id, cbas_enc** out);
+void cbas_enc_destroy(cbas_enc* h);
+
+/* DinoEncoder.forward on a device tensor: x (n,1,H,W) float32 in [0,1] (gray; replicated to 3
+ * identical channels by the reference, folded into the patch weights here).  Writes CLS rows:
+ * cls_f32_dev (n,D) and/or cls_f16_dev (n,D) IEEE half; either may be NULL.  n <= max_batch. */
+int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int height, int width,
+                         float* cls_f32_dev, uint16_t* cls_f16_dev, void* stream);
+
+/* Same from uint8 pixels already in HBM.  Pixel (f,y,x) is read at
+ * frames_dev[f*frame_stride + y*row_stride + x*pixel_stride]; for decord-style (n,H,W,3) RGB pass
+ * frames_dev = base+1, pixel_stride=3, row_stride=3*W, frame_stride=3*H*W (green channel,
+ * backend/cbas.py:431); for a packed green plane pass 1, W, H*W.  value/255 is applied exactly. */
+int cbas_enc_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
+                        int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                        float* cls_f32_dev, uint16_t* cls_f16_dev, void* stream);
+
+/* Host-streamed form (one iteration of encode_file's chunk loop).  `slot` in [0, CBAS_ENC_SLOTS):
+ * submit copies the pixels host->HBM on the handle's copy stream (from pinned staging), encodes
+ * on the compute stream and copies the CLS rows back; wait blocks until that slot is done and
+ * writes n*D halves (and/or floats).  Submitting to slot s while s is busy is CBAS_ESTATE.
+ * Different slots overlap: copy(s+1) runs under compute(s). */
+#define CBAS_ENC_SLOTS 3
+int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
+                            int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride);
+int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, float* cls_f32_host);
+
+/* Bring-up/debug: run the forward pass only up to (layer, stage) and copy an internal buffer to
+ * the host.  stage: 0 embeddings (x), then per layer 1 LN1(h16) 2 QKV(qkv16) 3 attention(h16)
+ * 4 o_proj residual (x) 5 LN2 (h16) 6 up_proj+GELU (u16) 7 down_proj residual (x).
+ * which: 0 x f32 (rows,D)  1 h16 (rows,D)  2 qkv16 (rows,3D)  3 u16 (rows,F); rows = n*T. */
+int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
+                              int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                              int stop_layer, int stop_stage);
+int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes);
+
+/* ---- classifier head ---------------------------------------------------------------------- */
+
+/* Mirrors ClassifierLSTMDeltas.__init__ (backend/classifier_head.py:62-64). */
+typedef struct cbas_head_config {
+    int32_t in_features;        /* 768 (D of the encoder)     */
+    int32_t out_features;       /* C behaviours               */
+    int32_t seq_len;            /* 31                         */
+    int32_t bottleneck_dim;     /* 128                        */
+    int32_t lin0_dim;           /* 256                        */
+    int32_t lstm_hidden_size;   /* 64 (or 128)                */
+    int32_t center_window_size; /* 5                          */
+    float   ema_alpha;          /* 0.3                        */
+} cbas_head_config;
+
+/* float32 elements expected by cbas_head_create, in this order (state_dict names):
+ *   gate[1] attention_temp[1]
+ *   cls_bottleneck.0.weight[Bn*I] .bias[Bn]  delta_bottleneck.0.weight .bias  acc_bottleneck.0.weight .bias
+ *   cls_ln.weight[Bn] .bias[Bn]  delta_ln.weight .bias  acc_ln.weight .bias
+ *   lin0.0.weight[L0*3Bn] .bias[L0]
+ *   lin1.weight[C*I] .bias[C]
+ *   lstm.weight_ih_l0[4h*L0] weight_hh_l0[4h*h] bias_ih_l0[4h] bias_hh_l0[4h], then the same four _reverse
+ *   attention_head.weight[2h] .bias[1]
+ *   lin2.weight[C*2h] .bias[C]                                                                   */
+int64_t cbas_head_weights_count(const cbas_head_config* cfg);
+
+int cbas_head_create(const cbas_head_config* cfg, const float* weights_host, int64_t n_weights,
+                     int device_id, cbas_head** out);
+void cbas_head_destroy(cbas_head* h);
+
+/* ClassifierLSTMDeltas.forward: x_dev (n_windows, seq_len, in_features) float32 ->
+ * logits_dev (n_windows, C) and latent_dev (n_windows, 2h); either output may be NULL. */
+int cbas_head_forward_windows(cbas_head* h, const float* x_dev, int64_t n_windows,
+                              float* logits_dev, float* latent_dev, void* stream);
+
+/* The window loop of infer_file over one clip: cls_f16_dev (n_frames, in_features) IEEE half rows
+ * (what _cls.h5 holds) -> probs_dev (n_frames, C) = softmax(logits / max(1e-3, temperature)) and
+ * optionally logits_dev (n_frames, C).  Window i = rows i-half .. i+half clamped to the clip
+ * (replicate edge padding, backend/cbas.py:512-525). */
+int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, float temperature,
+                        float* probs_dev, float* logits_dev, void* stream);
+
+/* ---- misc --------------------------------------------------------------------------------- */
+
+const char* cbas_last_error(void);
+int cbas_abi_version(void);
+/* Device facts for reports: writes the gfx arch name (e.g. "gfx950"), CU count and HBM bytes. */
+int cbas_device_info(int device_id, char* arch_out, int arch_cap, int32_t* n_cu, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBAS_MI355X_H */

@@ -1,0 +1,363 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference and the ``transformers`` package); the
+GPU box never sees either — it gets the small ``.npz`` / ``.csv`` fixtures this script writes.
+
+What is imported from the reference (nothing is copied):
+  * ``backend/classifier_head.py``  -> ``ClassifierLSTMDeltas``            (head goldens)
+  * ``backend/cbas.py``             -> ``DinoEncoder``, ``encode_file``, ``infer_file``
+    (needs stub modules for the absent ``cv2`` / ``decord`` / ``h5py``; functional fakes for
+    ``decord.VideoReader`` and ``h5py.File`` are supplied here, backed by numpy)
+  * ``transformers`` ``DINOv3ViTModel`` (the third-party package holding the ViT arithmetic)
+
+Weights and input frames come from the counter-based generators in ``cbas_amd.weights`` /
+``cbas_amd.synth`` so they never need committing.
+
+Usage:  python tests/golden/make_goldens.py [--only NAME] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+REF = "/root/reference"
+
+import torch  # noqa: E402
+
+from cbas_amd import config as C  # noqa: E402
+from cbas_amd import weights as W  # noqa: E402
+from cbas_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+BEHAVIORS = ["eating", "drinking", "rearing", "climbing", "digging", "nesting", "resting", "grooming",
+             "exploring"]     # reference models/JonesLabModel/config.yaml:1-10
+
+ENC_SEED, HEAD_SEED = 1234, 4321
+
+
+# --------------------------------------------------------------------------------------------
+# numpy-backed fakes for the reference's missing IO dependencies
+# --------------------------------------------------------------------------------------------
+class _FakeAttrs(dict):
+    pass
+
+
+class _FakeDataset:
+    def __init__(self, shape, dtype):
+        self._a = np.zeros(shape, dtype=dtype)
+
+    @property
+    def shape(self):
+        return self._a.shape
+
+    def resize(self, size, axis=0):
+        new = np.zeros((size,) + self._a.shape[1:], dtype=self._a.dtype)
+        n = min(size, self._a.shape[0])
+        new[:n] = self._a[:n]
+        self._a = new
+
+    def __setitem__(self, k, v):
+        self._a[k] = v          # casts to the dataset dtype (f2), like h5py
+
+    def __getitem__(self, k):
+        return self._a[k]
+
+    def __len__(self):
+        return self._a.shape[0]
+
+
+_FAKE_FS: dict = {}
+
+
+class _FakeH5File:
+    def __init__(self, path, mode="r"):
+        self.path, self.mode = path, mode
+        if "w" in mode:
+            _FAKE_FS[path] = {"attrs": _FakeAttrs(), "dsets": {}}
+            open(path, "wb").close()         # so os.replace / os.path.exists behave
+        elif path not in _FAKE_FS:
+            raise OSError(f"no such fake h5 file: {path}")
+        self._n = _FAKE_FS[path]
+        self.attrs = self._n["attrs"]
+
+    def create_dataset(self, name, shape, maxshape=None, dtype="f4", chunks=None):
+        d = _FakeDataset(shape, np.dtype(dtype))
+        d.maxshape, d.chunks = maxshape, chunks
+        self._n["dsets"][name] = d
+        return d
+
+    def __getitem__(self, name):
+        return self._n["dsets"][name]
+
+    def flush(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _FakeBatch:
+    def __init__(self, a):
+        self._a = a
+
+    def asnumpy(self):
+        return self._a
+
+
+class _FakeVideoReader:
+    """decord.VideoReader(path, ctx) fake: 'path' indexes a registry of in-memory clips."""
+    CLIPS: dict = {}
+
+    def __init__(self, path, ctx=None):
+        self._f = self.CLIPS[path]
+
+    def __len__(self):
+        return self._f.shape[0]
+
+    def get_batch(self, idx):
+        return _FakeBatch(self._f[list(idx)])
+
+
+def import_reference():
+    for name in ("cv2", "decord", "h5py"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["cv2"].VideoCapture = object
+    sys.modules["decord"].VideoReader = _FakeVideoReader
+    sys.modules["decord"].cpu = lambda i=0: None
+    sys.modules["h5py"].File = _FakeH5File
+    for p in (REF, os.path.join(REF, "backend")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import classifier_head  # noqa
+    import cbas  # noqa
+    return cbas, classifier_head
+
+
+def _real_replace(src, dst):
+    if src in _FAKE_FS:
+        _FAKE_FS[dst] = _FAKE_FS.pop(src)
+    _os_replace(src, dst)
+
+
+_os_replace = os.replace
+
+
+# --------------------------------------------------------------------------------------------
+def hf_model(cfg: C.ViTConfig, weights):
+    from transformers import DINOv3ViTConfig, DINOv3ViTModel
+    hcfg = DINOv3ViTConfig(
+        patch_size=cfg.patch_size, image_size=cfg.image_size, hidden_size=cfg.hidden_size,
+        intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, num_register_tokens=cfg.num_register_tokens,
+        layer_norm_eps=cfg.layer_norm_eps, rope_theta=cfg.rope_theta)
+    hcfg._attn_implementation = "eager"
+    m = DINOv3ViTModel(hcfg).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("inv_freq" in k for k in missing), missing
+    return m
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def g_tiny(out):
+    """Tiny ViT with per-stage taps (via HF hidden_states) — kernel-by-kernel bring-up."""
+    cfg = C.VIT_TINY
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    m = hf_model(cfg, w)
+    frames = synth.cage_frames(7, 4, 64, 64)
+    g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()
+    px = g.unsqueeze(1).repeat(1, 3, 1, 1)
+    o = m(px, output_hidden_states=True)
+    hs = [h.numpy() for h in o.hidden_states]
+    np.savez_compressed(os.path.join(out, "vit_tiny.npz"),
+                        frames_sha=sha(frames), n=4, height=64, width=64, frame_seed=7,
+                        embeddings=hs[0], layer0=hs[1], layer1=hs[2],
+                        last_hidden=o.last_hidden_state.numpy())
+
+
+def _cls_golden(out, name, cfg, n, H, W_, frame_seed, via_wrapper=False, kind="cage"):
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    frames = (synth.cage_frames if kind == "cage" else synth.noise_frames)(frame_seed, n, H, W_)
+    g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()           # cbas.py:431
+    if via_wrapper:
+        cbas, _ = import_reference()
+        with tempfile.TemporaryDirectory() as td:
+            m = hf_model(cfg, w)
+            m.save_pretrained(td)
+            enc = cbas.DinoEncoder(td, device="cpu")                   # reference wrapper, cbas.py:650-677
+            cls = enc(g.unsqueeze(1)).squeeze(1).numpy()               # cbas.py:435-436
+    else:
+        m = hf_model(cfg, w)
+        cls = torch.cat([m(g[i:i + 2].unsqueeze(1).repeat(1, 3, 1, 1)).last_hidden_state[:, 0]
+                         for i in range(0, n, 2)]).numpy()
+    np.savez_compressed(os.path.join(out, f"{name}.npz"), cls=cls.astype(np.float32),
+                        frames_sha=sha(frames), n=n, height=H, width=W_, frame_seed=frame_seed, kind=kind)
+    print(name, cls.shape, float(np.abs(cls).mean()))
+
+
+def g_vits(out):
+    _cls_golden(out, "vits16_224", C.VIT_S16, 8, 224, 224, 11)
+
+
+def g_vitb(out):
+    _cls_golden(out, "vitb16_224", C.VIT_B16, 8, 224, 224, 12, via_wrapper=True)
+
+
+def g_vitb_noise(out):
+    _cls_golden(out, "vitb16_224_noise", C.VIT_B16, 4, 224, 224, 0, kind="noise")
+
+
+def g_vitb256(out):
+    _cls_golden(out, "vitb16_256", C.VIT_B16, 4, 256, 256, 13)
+
+
+def g_vitl(out):
+    _cls_golden(out, "vitl16_224", C.VIT_L16, 4, 224, 224, 14)
+
+
+def g_vitl518(out):
+    _cls_golden(out, "vitl16_518", C.VIT_L16, 2, 518, 518, 15)
+
+
+def ref_head(classifier_head, hcfg: C.HeadConfig, hw):
+    m = classifier_head.ClassifierLSTMDeltas(
+        in_features=hcfg.in_features, out_features=hcfg.out_features, seq_len=hcfg.seq_len,
+        lstm_hidden_size=hcfg.lstm_hidden_size, lstm_layers=hcfg.lstm_layers).eval()
+    res = m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in hw.items()}, strict=True)
+    return m
+
+
+def g_head(out):
+    _, classifier_head = import_reference()
+    for tag, h, C_, I in (("h64", 64, 9, 768), ("h128", 128, 5, 768), ("h64_d384", 64, 9, 384)):
+        hcfg = C.HeadConfig(in_features=I, out_features=C_, lstm_hidden_size=h)
+        hw = W.synth_head_weights(hcfg, HEAD_SEED)
+        m = ref_head(classifier_head, hcfg, hw)
+        seq = synth.cls_walk(21, 64 + 30, I).astype(np.float32)
+        x = np.stack([seq[i:i + 31] for i in range(64)])
+        logits, latent = m(torch.from_numpy(x))
+        np.savez_compressed(os.path.join(out, f"head_{tag}.npz"), logits=logits.numpy(), latent=latent.numpy(),
+                            x_sha=sha(x), walk_seed=21)
+        print("head", tag, logits.shape, latent.shape)
+
+
+def g_infer(out):
+    """cbas.infer_file end to end on synthetic _cls.h5 contents: edge padding, halo chunking,
+    temperature clamp, and the CSV text pandas writes."""
+    cbas, classifier_head = import_reference()
+    hcfg = C.HeadConfig()
+    hw = W.synth_head_weights(hcfg, HEAD_SEED)
+    m = ref_head(classifier_head, hcfg, hw)
+    os.replace = _real_replace
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for n, temp in ((1, 1.0), (10, 1.0), (31, 1.0), (64, 0.7), (700, 1.0), (20017, 1.3), (40, 1e-6)):
+            p = os.path.join(td, f"clip{n}_cls.h5")
+            cls = synth.cls_walk(100 + n, n, 768)
+            with _FakeH5File(p, "w") as f:
+                d = f.create_dataset("cls", shape=(n, 768), dtype="f2")
+                d[:] = cls
+            o = cbas.infer_file(p, m, "gold", BEHAVIORS, 31, device=torch.device("cpu"), temperature=temp)
+            assert o is not None
+            import pandas as pd
+            probs = pd.read_csv(o).to_numpy(dtype=np.float64)
+            with open(o, "r") as fh:
+                text = fh.read()
+            res[f"probs_{n}"] = probs.astype(np.float32)
+            res[f"temp_{n}"] = np.float64(temp)
+            res[f"cls_sha_{n}"] = sha(cls)
+            if n <= 64:
+                res[f"csv_{n}"] = np.frombuffer(text.encode(), dtype=np.uint8)
+            print("infer", n, probs.shape)
+    np.savez_compressed(os.path.join(out, "infer_file.npz"), **res)
+
+
+def g_e2e(out):
+    """BASELINE config 1: ViT-S/16, 64 frames 224^2, batch 8 -> CLS -> f16 -> infer_file, C=9."""
+    cbas, classifier_head = import_reference()
+    cfg = C.VIT_S16
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    m = hf_model(cfg, w)
+    frames = synth.cage_frames(3, 64, 224, 224)
+    g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()
+    cls = torch.cat([m(g[i:i + 8].unsqueeze(1).repeat(1, 3, 1, 1)).last_hidden_state[:, 0]
+                     for i in range(0, 64, 8)]).numpy()
+    hcfg = C.HeadConfig(in_features=384)
+    hw = W.synth_head_weights(hcfg, HEAD_SEED)
+    hm = ref_head(classifier_head, hcfg, hw)
+    os.replace = _real_replace
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "e2e_cls.h5")
+        with _FakeH5File(p, "w") as f:
+            d = f.create_dataset("cls", shape=(64, 384), dtype="f2")
+            d[:] = cls                                   # f32 -> f2 cast on write, cbas.py:438
+            cls16 = d[:].copy()
+        # infer_file hard-codes nothing about 768 (the head is built with in_features=384 here)
+        o = cbas.infer_file(p, hm, "gold", BEHAVIORS, 31, device=torch.device("cpu"), temperature=1.0)
+        import pandas as pd
+        probs = pd.read_csv(o).to_numpy(dtype=np.float64).astype(np.float32)
+    np.savez_compressed(os.path.join(out, "e2e_vits16.npz"), cls=cls.astype(np.float32), cls_f16=cls16,
+                        probs=probs, labels=probs.argmax(1), frames_sha=sha(frames), frame_seed=3, n=64)
+    print("e2e labels", np.bincount(probs.argmax(1), minlength=9))
+
+
+def g_encode_file(out):
+    """cbas.encode_file on a fake 'video' (decord/h5py fakes): pins chunking (CHUNK_SIZE=512 with a
+    ragged tail), the f2 cast and the returned path.  Uses the tiny-D wrapper-compatible config
+    (the reference hard-codes 768, so D must be 768: use ViT-B width with 1 layer to stay small)."""
+    cbas, _ = import_reference()
+    cfg = C.ViTConfig(hidden_size=768, intermediate_size=1536, num_hidden_layers=1, num_attention_heads=12,
+                      image_size=32)
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    os.replace = _real_replace
+    with tempfile.TemporaryDirectory() as td:
+        m = hf_model(cfg, w)
+        m.save_pretrained(td)
+        enc = cbas.DinoEncoder(td, device="cpu")
+        frames = synth.cage_frames(5, 600, 32, 32)
+        vp = os.path.join(td, "vid.mp4")
+        _FakeVideoReader.CLIPS[vp] = frames
+        ticks = []
+        o = cbas.encode_file(enc, vp, progress_callback=ticks.append)
+        assert o == os.path.join(td, "vid_cls.h5"), o
+        d = _FAKE_FS[o]["dsets"]["cls"]
+        np.savez_compressed(os.path.join(out, "encode_file_b1layer.npz"), cls_f16=d[:].copy(),
+                            ticks=np.array(ticks), frames_sha=sha(frames), frame_seed=5, n=600,
+                            chunks=np.array(d.chunks), maxshape1=d.maxshape[1])
+        print("encode_file", d.shape, ticks)
+
+
+ALL = {"tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
+       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "infer": g_infer, "e2e": g_e2e,
+       "encode_file": g_encode_file}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=HERE)
+    a = ap.parse_args()
+    for k, fn in ALL.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        fn(a.out)
