@@ -1,7 +1,233 @@
-// placeholder until the head kernels land (replaced in the next commit)
+// C-ABI: classifier-head handle (ClassifierLSTMDeltas + the window loop of infer_file).
+// See include/cbas_mi355x.h for the contract and the reference lines each entry point replaces.
+#include <math.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
 #include "api_common.h"
-extern "C" int64_t cbas_head_weights_count(const cbas_head_config*) { return -1; }
-extern "C" int cbas_head_create(const cbas_head_config*, const float*, int64_t, int, cbas_head**) { return cbas_fail(CBAS_EINVAL, "head not built"); }
-extern "C" void cbas_head_destroy(cbas_head*) {}
-extern "C" int cbas_head_forward_windows(cbas_head*, const float*, int64_t, float*, float*, void*) { return cbas_fail(CBAS_EINVAL, "head not built"); }
-extern "C" int cbas_head_infer_f16(cbas_head*, const uint16_t*, int64_t, float, float*, float*, void*) { return cbas_fail(CBAS_EINVAL, "head not built"); }
+#include "kernels.h"
+
+namespace {
+constexpr int64_t WCHUNK = 4096;     // windows per pass (bounds the workspace at ~1 GB for h=64)
+}
+
+struct cbas_head {
+    cbas_head_config cfg;
+    int device;
+    HeadDims d;
+    // device weights
+    float* wbuf = nullptr;           // one arena
+    const float *w_proj, *b_bott, *ln_w, *ln_b, *b_lin1, *w_lin0, *b_lin0, *w_ih, *b_gate, *w_hh, *w_att, *w_lin2, *b_lin2;
+    float b_att, gate_sigmoid, att_temp;
+    // workspaces
+    float *rows32 = nullptr, *proj = nullptr, *aug = nullptr, *xl = nullptr, *gin = nullptr, *hout = nullptr,
+          *lin_logits = nullptr;
+    int64_t proj_rows_cap = 0;
+};
+
+namespace {
+
+int64_t head_weights_count(const cbas_head_config& c) {
+    const int64_t I = c.in_features, C = c.out_features, Bn = c.bottleneck_dim, L0 = c.lin0_dim, h = c.lstm_hidden_size;
+    return 2 + 3 * (Bn * I + Bn) + 3 * 2 * Bn + (L0 * 3 * Bn + L0) + (C * I + C) + 2 * (4 * h * L0 + 4 * h * h + 8 * h) +
+           (2 * h + 1) + (C * 2 * h + C);
+}
+
+// One chunk of windows through expand -> lin0 -> centre -> in-proj -> recurrent -> pool.
+int run_chunk(cbas_head* h, int64_t nw, int sliding, int64_t w0, int64_t r0, int64_t n_frames, float temperature,
+              float* probs, float* logits, float* latent, hipStream_t st) {
+    const HeadDims& d = h->d;
+    LAUNCH_TRY(launch_head_expand(h->proj, d, h->b_bott, h->ln_w, h->ln_b, h->b_lin1, nw, sliding, w0, r0, n_frames,
+                                  h->aug, h->lin_logits, st));
+    Gemm32Params g{};
+    g.A = h->aug; g.lda = 3 * d.Bn; g.W = h->w_lin0; g.bias = h->b_lin0; g.out = h->xl; g.ldo = d.L0;
+    g.M = nw * d.T; g.N = d.L0; g.N_alloc = d.L0; g.K = 3 * d.Bn;
+    LAUNCH_TRY(launch_gemm_f32(g, 1, st));
+    LAUNCH_TRY(launch_head_centre(h->xl, nw, d.T, d.L0, st));
+    Gemm32Params q{};
+    q.A = h->xl; q.lda = d.L0; q.W = h->w_ih; q.bias = h->b_gate; q.out = h->gin; q.ldo = 8 * d.h;
+    q.M = nw * d.T; q.N = 8 * d.h; q.N_alloc = 8 * d.h; q.K = d.L0;
+    LAUNCH_TRY(launch_gemm_f32(q, 0, st));
+    LAUNCH_TRY(launch_head_lstm(h->gin, h->w_hh, d, nw, h->hout, st));
+    LAUNCH_TRY(launch_head_pool(h->hout, h->lin_logits, d, h->w_att, h->b_att, h->att_temp, h->w_lin2, h->b_lin2,
+                                h->gate_sigmoid, temperature, nw, probs, logits, latent, st));
+    return CBAS_OK;
+}
+
+int project(cbas_head* h, const float* rows32, int64_t n_rows, hipStream_t st) {
+    const HeadDims& d = h->d;
+    Gemm32Params p{};
+    p.A = rows32; p.lda = d.I; p.W = h->w_proj; p.bias = nullptr; p.out = h->proj; p.ldo = d.NPROJ;
+    p.M = n_rows; p.N = d.NPROJ; p.N_alloc = d.NPROJ; p.K = d.I;
+    LAUNCH_TRY(launch_gemm_f32(p, 0, st));
+    return CBAS_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t cbas_head_weights_count(const cbas_head_config* cfg) { return cfg ? head_weights_count(*cfg) : -1; }
+
+extern "C" void cbas_head_destroy(cbas_head* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {h->wbuf, h->rows32, h->proj, h->aug, h->xl, h->gin, h->hout, h->lin_logits};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete h;
+}
+
+extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weights_host, int64_t n_weights,
+                                int device_id, cbas_head** out) {
+    if (!cfg || !weights_host || !out) return cbas_fail(CBAS_EINVAL, "null argument");
+    *out = nullptr;
+    const cbas_head_config& c = *cfg;
+    const int64_t I = c.in_features, C = c.out_features, Bn = c.bottleneck_dim, L0 = c.lin0_dim, hh = c.lstm_hidden_size;
+    const int T = c.seq_len;
+    if (I <= 0 || I % 32) return cbas_fail(CBAS_EINVAL, "in_features=%lld must be a positive multiple of 32", (long long)I);
+    if (C <= 0 || C > 64) return cbas_fail(CBAS_EINVAL, "out_features=%lld outside [1,64]", (long long)C);
+    if (Bn % 64 || Bn <= 0 || Bn > 256 || (3 * Bn) % 32) return cbas_fail(CBAS_EINVAL, "bottleneck_dim=%lld unsupported", (long long)Bn);
+    if (L0 % 32 || L0 <= 0) return cbas_fail(CBAS_EINVAL, "lin0_dim=%lld must be a multiple of 32", (long long)L0);
+    if (hh != 64 && hh != 128) return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%lld: only 64 and 128 are built", (long long)hh);
+    if (T < 3 || T > 101) return cbas_fail(CBAS_EINVAL, "seq_len=%d outside [3,101]", T);
+    const int hsl = T / 2, sw = c.center_window_size;
+    const int lo = hsl - sw > 0 ? hsl - sw : 0, hi = hsl + sw + 1 < T ? hsl + sw + 1 : T;
+    if (lo >= hi) return cbas_fail(CBAS_EINVAL, "empty centre window (seq_len=%d, center_window_size=%d)", T, sw);
+    if (n_weights != head_weights_count(c))
+        return cbas_fail(CBAS_EINVAL, "weights blob has %lld floats, config needs %lld", (long long)n_weights,
+                         (long long)head_weights_count(c));
+    HIP_TRY(hipSetDevice(device_id));
+
+    cbas_head* h = new (std::nothrow) cbas_head();
+    if (!h) return cbas_fail(CBAS_ENOMEM, "out of host memory");
+    h->cfg = c; h->device = device_id;
+    HeadDims& d = h->d;
+    d.I = (int)I; d.C = (int)C; d.T = T; d.Bn = (int)Bn; d.L0 = (int)L0; d.h = (int)hh; d.lo = lo; d.hi = hi;
+    d.NPROJ = (int)round_up(3 * Bn + C, 4);
+    d.alpha = c.ema_alpha;
+
+    // ---- repack the state dict into the layouts the kernels read --------------------------------
+    const float* p = weights_host;
+    const float gate = p[0], att_temp_raw = p[1];
+    p += 2;
+    const float* bw[3]; const float* bb[3];
+    for (int s = 0; s < 3; ++s) { bw[s] = p; p += Bn * I; bb[s] = p; p += Bn; }
+    const float* lnw[3]; const float* lnb[3];
+    for (int s = 0; s < 3; ++s) { lnw[s] = p; p += Bn; lnb[s] = p; p += Bn; }
+    const float* lin0_w = p; p += L0 * 3 * Bn;
+    const float* lin0_b = p; p += L0;
+    const float* lin1_w = p; p += C * I;
+    const float* lin1_b = p; p += C;
+    const float *wih[2], *whh[2], *bih[2], *bhh[2];
+    for (int dir = 0; dir < 2; ++dir) {
+        wih[dir] = p; p += 4 * hh * L0;
+        whh[dir] = p; p += 4 * hh * hh;
+        bih[dir] = p; p += 4 * hh;
+        bhh[dir] = p; p += 4 * hh;
+    }
+    const float* att_w = p; p += 2 * hh;
+    const float att_b = *p; p += 1;
+    const float* lin2_w = p; p += C * 2 * hh;
+    const float* lin2_b = p; p += C;
+    if (p - weights_host != n_weights) { delete h; return cbas_fail(CBAS_EINVAL, "internal blob layout mismatch"); }
+
+    std::vector<float> arena;
+    auto put = [&](const float* src, int64_t n) { size_t o = arena.size(); arena.insert(arena.end(), src, src + n); return o; };
+    auto pad4 = [&]() { while (arena.size() % 4) arena.push_back(0.f); };
+    // w_proj rows: cls | delta | acc | lin1 | zero rows up to NPROJ
+    const size_t o_proj = arena.size();
+    for (int s = 0; s < 3; ++s) put(bw[s], Bn * I);
+    put(lin1_w, C * I);
+    arena.resize(o_proj + (size_t)d.NPROJ * I, 0.f);
+    const size_t o_bbott = arena.size(); for (int s = 0; s < 3; ++s) put(bb[s], Bn);
+    const size_t o_lnw = arena.size(); for (int s = 0; s < 3; ++s) put(lnw[s], Bn);
+    const size_t o_lnb = arena.size(); for (int s = 0; s < 3; ++s) put(lnb[s], Bn);
+    const size_t o_blin1 = put(lin1_b, C); pad4();
+    const size_t o_wlin0 = put(lin0_w, L0 * 3 * Bn);
+    const size_t o_blin0 = put(lin0_b, L0); pad4();
+    const size_t o_wih = arena.size(); put(wih[0], 4 * hh * L0); put(wih[1], 4 * hh * L0);
+    const size_t o_bgate = arena.size();
+    for (int dir = 0; dir < 2; ++dir)
+        for (int64_t i = 0; i < 4 * hh; ++i) arena.push_back(bih[dir][i] + bhh[dir][i]);
+    const size_t o_whh = arena.size(); put(whh[0], 4 * hh * hh); put(whh[1], 4 * hh * hh);
+    const size_t o_watt = put(att_w, 2 * hh); pad4();
+    const size_t o_wlin2 = put(lin2_w, C * 2 * hh); pad4();
+    const size_t o_blin2 = put(lin2_b, C); pad4();
+
+    h->gate_sigmoid = (float)(1.0 / (1.0 + exp(-(double)gate)));
+    // F.softplus(x) + 1e-3 (beta=1, threshold=20), classifier_head.py:142
+    h->att_temp = (att_temp_raw > 20.f ? att_temp_raw : (float)log1p(exp((double)att_temp_raw))) + 1e-3f;
+    h->b_att = att_b;
+
+#define CREATE_TRY(expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            cbas_fail(CBAS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            cbas_head_destroy(h);                                                                         \
+            return _e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP;                                   \
+        }                                                                                                 \
+    } while (0)
+    CREATE_TRY(hipMalloc(&h->wbuf, arena.size() * sizeof(float)));
+    CREATE_TRY(hipMemcpy(h->wbuf, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->w_proj = h->wbuf + o_proj; h->b_bott = h->wbuf + o_bbott; h->ln_w = h->wbuf + o_lnw; h->ln_b = h->wbuf + o_lnb;
+    h->b_lin1 = h->wbuf + o_blin1; h->w_lin0 = h->wbuf + o_wlin0; h->b_lin0 = h->wbuf + o_blin0;
+    h->w_ih = h->wbuf + o_wih; h->b_gate = h->wbuf + o_bgate; h->w_hh = h->wbuf + o_whh;
+    h->w_att = h->wbuf + o_watt; h->w_lin2 = h->wbuf + o_wlin2; h->b_lin2 = h->wbuf + o_blin2;
+
+    h->proj_rows_cap = WCHUNK * T;       // explicit-window mode needs WCHUNK*T rows, sliding WCHUNK+T
+    CREATE_TRY(hipMalloc(&h->rows32, (WCHUNK + T) * I * sizeof(float)));   // sliding mode: chunk + halo rows
+    CREATE_TRY(hipMalloc(&h->proj, h->proj_rows_cap * d.NPROJ * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->aug, WCHUNK * T * 3 * Bn * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->xl, WCHUNK * T * L0 * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->gin, WCHUNK * T * 8 * hh * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->hout, WCHUNK * (hi - lo) * 2 * hh * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->lin_logits, WCHUNK * C * sizeof(float)));
+#undef CREATE_TRY
+    *out = h;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_head_forward_windows(cbas_head* h, const float* x_dev, int64_t n_windows, float* logits_dev,
+                                         float* latent_dev, void* stream) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null head handle");
+    if (!x_dev || n_windows <= 0) return cbas_fail(CBAS_EINVAL, "x_dev NULL or n_windows <= 0");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const HeadDims& d = h->d;
+    for (int64_t w0 = 0; w0 < n_windows; w0 += WCHUNK) {
+        const int64_t nw = n_windows - w0 < WCHUNK ? n_windows - w0 : WCHUNK;
+        int rc = project(h, x_dev + w0 * d.T * d.I, nw * d.T, st);
+        if (rc) return rc;
+        rc = run_chunk(h, nw, 0, 0, 0, 0, 1.0f, nullptr, logits_dev ? logits_dev + w0 * d.C : nullptr,
+                       latent_dev ? latent_dev + w0 * 2 * d.h : nullptr, st);
+        if (rc) return rc;
+    }
+    return CBAS_OK;
+}
+
+extern "C" int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, float temperature,
+                                   float* probs_dev, float* logits_dev, void* stream) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null head handle");
+    if (!cls_f16_dev || n_frames <= 0) return cbas_fail(CBAS_EINVAL, "cls_f16_dev NULL or n_frames <= 0");
+    if (!probs_dev && !logits_dev) return cbas_fail(CBAS_EINVAL, "no output requested");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const HeadDims& d = h->d;
+    const int half = d.T / 2;
+    for (int64_t w0 = 0; w0 < n_frames; w0 += WCHUNK) {
+        const int64_t nw = n_frames - w0 < WCHUNK ? n_frames - w0 : WCHUNK;
+        // rows needed: frames [w0-half, w0+nw+half) clipped to the clip (edge replicate = clamped index)
+        const int64_t r0 = w0 - half > 0 ? w0 - half : 0;
+        const int64_t r1 = w0 + nw + half < n_frames ? w0 + nw + half : n_frames;
+        const int64_t nr = r1 - r0;
+        LAUNCH_TRY(launch_f16_to_f32((const f16*)cls_f16_dev + r0 * d.I, h->rows32, nr * d.I, st));
+        int rc = project(h, h->rows32, nr, st);
+        if (rc) return rc;
+        rc = run_chunk(h, nw, 1, w0, r0, n_frames, temperature, probs_dev ? probs_dev + w0 * d.C : nullptr,
+                       logits_dev ? logits_dev + w0 * d.C : nullptr, nullptr, st);
+        if (rc) return rc;
+    }
+    return CBAS_OK;
+}

@@ -68,36 +68,41 @@ int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_
 int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
-// classifier head kernels (fp32)
+// classifier head (all fp32)
 // ---------------------------------------------------------------------------------------------
+struct Gemm32Params {
+    const float* A; int64_t lda;   // [M][lda], first K columns used
+    const float* W;                // [N_alloc][K]
+    const float* bias;             // [N] or nullptr
+    float* out; int64_t ldo;       // [M][ldo]
+    int64_t M; int N; int N_alloc; int K;   // N % 4 == 0, K % 32 == 0
+};
+int launch_gemm_f32(const Gemm32Params& p, int gelu, hipStream_t stream);
+
 struct HeadDims {
-    int I, C, T, Bn, L0, h, sw;   // in_features, classes, seq_len, bottleneck, lin0 dim, lstm hidden, centre half-width
+    int I, C, T, Bn, L0, h;   // in_features, classes, seq_len, bottleneck dim, lin0 dim, lstm hidden
+    int lo, hi;               // centre window [lo, hi) in window time
+    int NPROJ;                // projection width: 3*Bn + C rounded up to a multiple of 4
     float alpha;
 };
-struct HeadWeightsDev {
-    // projection matrix for the per-row stage: [NP][I] rows = cls(Bn) | delta(Bn) | acc(Bn) | lin1(C), zero padded to NP
-    const float* w_proj; int NP;
-    const float* b_bott;      // [3*Bn]   bottleneck biases
-    const float* ln_w;        // [3*Bn]
-    const float* ln_b;        // [3*Bn]
-    const float* b_lin1;      // [C]
-    const float* w_lin0;      // [L0][3*Bn]
-    const float* b_lin0;      // [L0]
-    const float* w_ih;        // [2][4h][L0]
-    const float* w_hh;        // [2][4h][h]
-    const float* b_gate;      // [2][4h]  (bias_ih + bias_hh)
-    const float* w_att;       // [2h]
-    float b_att;
-    const float* w_lin2;      // [C][2h]
-    const float* b_lin2;      // [C]
-    float gate_sigmoid;       // sigmoid(gate)
-    float att_temp;           // softplus(attention_temp) + 1e-3
-};
 
-// rows (fp16 or fp32, [n_rows][I]) -> proj [n_rows][NP] fp32
-int launch_head_project(const void* rows, int rows_are_f16, int64_t n_rows, const HeadDims& d,
-                        const HeadWeightsDev& w, float* proj, hipStream_t stream);
-// per-window stage.  sliding != 0: window i = rows clamp(i-half .. i+half); else window i = rows i*T .. i*T+T-1.
-int launch_head_windows(const float* proj, int64_t n_rows, int64_t n_windows, int sliding, const HeadDims& d,
-                        const HeadWeightsDev& w, float temperature, float* probs, float* logits,
-                        float* latent, hipStream_t stream);
+// fp16 rows -> fp32 rows (exact), n elements
+int launch_f16_to_f32(const f16* src, float* dst, int64_t n, hipStream_t stream);
+
+// Per-window EMA / delta / acceleration on the PROJECTED rows, + bias, GELU, LayerNorm -> aug[w][t][3Bn];
+// also the linear branch lin_logits[w][C] = mean_{t in centre}(EMA(proj_lin1)_t) + b_lin1.
+// sliding: proj row of (w,t) = clamp(w0 + w + t - T/2, 0, n_frames-1) - r0 ; else (w*T + t).
+int launch_head_expand(const float* proj, const HeadDims& d, const float* b_bott, const float* ln_w,
+                       const float* ln_b, const float* b_lin1, int64_t n_windows, int sliding, int64_t w0,
+                       int64_t r0, int64_t n_frames, float* aug, float* lin_logits, hipStream_t stream);
+// xl[w][t][:] -= mean_t xl[w][t][:]
+int launch_head_centre(float* xl, int64_t n_windows, int T, int L0, hipStream_t stream);
+// Recurrent half of the BiLSTM: gin[w][t][dir*4h + gate*h + unit] holds W_ih x + b; runs fwd steps
+// 0..hi-1 and bwd steps T-1..lo, writes hout[w][t-lo][dir*h + unit] for t in [lo,hi).
+int launch_head_lstm(const float* gin, const float* w_hh, const HeadDims& d, int64_t n_windows, float* hout,
+                     hipStream_t stream);
+// attention pooling + lin2 + gate lerp + softmax(logits / max(1e-3, T))
+int launch_head_pool(const float* hout, const float* lin_logits, const HeadDims& d, const float* w_att,
+                     float b_att, float att_temp, const float* w_lin2, const float* b_lin2, float gate_sigmoid,
+                     float temperature, int64_t n_windows, float* probs, float* logits, float* latent,
+                     hipStream_t stream);
