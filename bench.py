@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the streamed encode + classify path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): DINOv3 ViT-B/16, synthetic 224x224 RGB uint8 clip resident in
+HBM, batch 64, chunked encode -> fp16 CLS -> sliding-window BiLSTM head (C=9, seq_len 31).
+One *step* = one 64-frame batch through the encoder, plus the head over every frame whose
+31-frame window has become complete (classified in groups, the tail inside the timed region).
+Weights are synthetic (seeded, counter-based): the real checkpoints are gated and there is no
+network.  With N > 1 each rank streams its own clip (weak scaling, no data-path collective) and the
+output rows are gathered to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from cbas_amd import config as C  # noqa: E402
+from cbas_amd import dist as cdist  # noqa: E402
+from cbas_amd import weights as W  # noqa: E402
+from cbas_amd import synth  # noqa: E402
+
+METRIC = "frames/sec DINOv3-B/16 224px encode+LSTM classify"
+MFMA_F16_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+BEHAVIORS = 9
+SEQ_LEN = 31
+
+
+def cpu_baseline(model: str, hw: int, frames: int, batch: int) -> dict:
+    """The oracle (CPU float32 restatement of the reference path) timed on this box's host cores,
+    on a bounded sample of the same workload.  Never used as the product path."""
+    from oracle import pipeline_oracle as PO
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    cfg = C.NAMED_VIT[model]
+    hcfg = C.HeadConfig(in_features=cfg.hidden_size, out_features=BEHAVIORS, seq_len=SEQ_LEN)
+    enc_w = W.synth_encoder_weights(cfg, 1234)
+    head_w = W.synth_head_weights(hcfg, 4321)
+    fr = synth.noise_frames(0, frames, hw, hw)
+    PO.encode_and_classify(fr[:batch], enc_w, cfg, head_w, SEQ_LEN, batch)        # warm-up batch
+    t0 = time.perf_counter()
+    PO.encode_and_classify(fr, enc_w, cfg, head_w, SEQ_LEN, batch)
+    dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{frames} frames of the same workload ({model} {hw}x{hw}, batch {batch}, fp32 numpy/BLAS "
+                      f"oracle incl. LSTM head), {dt:.1f} s wall"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=157)        # 157 x 64 = 10 048 frames: the 10k-frame clip
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="vitb16")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--hw", type=int, default=224)
+    ap.add_argument("--precision", type=int, default=0)
+    ap.add_argument("--cpu-frames", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = cdist.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from cbas_amd.encoder import DinoEncoder
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from cbas_amd.stream import ClipStream
+
+    cfg = C.NAMED_VIT[args.model]
+    hcfg = C.HeadConfig(in_features=cfg.hidden_size, out_features=BEHAVIORS, seq_len=SEQ_LEN)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), device, max_batch=args.batch,
+                                   max_frame=(args.hw, args.hw), precision=args.precision)
+    head = ClassifierLSTMDeltas(cfg.hidden_size, BEHAVIORS, seq_len=SEQ_LEN)
+    head.load_state_dict(W.synth_head_weights(hcfg, 4321))
+    head.to(device)
+
+    B, K, Wm = args.batch, args.steps, args.warmup
+    # synthetic clip resident in HBM before the timed region: uniform uint8 RGB, decord layout (n,H,W,3)
+    n_res = min(K, 160) * B                      # ~10k frames resident; longer runs wrap around
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1000 + rank)
+    clip = torch.randint(0, 256, (n_res, args.hw, args.hw, 3), dtype=torch.uint8, device=device, generator=gen)
+    stream = ClipStream(enc, head, capacity=max(K, Wm) * B, classify_every=1024)
+
+    def run(steps: int):
+        stream.reset()
+        for s in range(steps):
+            o = (s * B) % n_res
+            stream.push_u8(clip[o:o + B])
+        return stream.finish()
+
+    def gather(cls16, probs):
+        if world > 1:
+            cdist.gather_rows([cls16], dst=0)
+            cdist.gather_rows([probs], dst=0)
+
+    # warm-up (also builds the RCCL communicator and the rope table outside the timed region)
+    c16, pr = run(max(Wm, 1))
+    gather(c16, pr)
+    torch.cuda.synchronize(device)
+
+    if not args.no_kernel_timing:
+        enc.profile(True)
+    cdist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    c16, pr = run(K)
+    gather(c16, pr)
+    torch.cuda.synchronize(device)
+    cdist.barrier()
+    dt = time.perf_counter() - t0
+    dt = cdist.max_over_ranks(dt, device)
+    prof = enc.profile_read() if not args.no_kernel_timing else {}
+    enc.profile(False)
+
+    if rank != 0:
+        return
+    frames_total = K * B * world
+    value = frames_total / dt
+    flops_frame = cfg.flops_per_frame(args.hw, args.hw) + hcfg.flops_per_frame_naive()
+
+    out = {
+        "metric": METRIC, "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"DINOv3 ViT-{args.model[3:].upper()} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
+                               f"batch={B}, chunked encode + BiLSTM head (C={BEHAVIORS}, seq_len={SEQ_LEN})",
+                   "batch": B, "frames_per_gpu": K * B, "frame": [args.hw, args.hw], "parallelism": f"clip-per-gpu x{world}",
+                   "weights": "synthetic (seeded counter-based generator)", "operands": "fp16 MFMA, fp32 accumulate/residual; head fp32",
+                   "encoder_gflop_per_frame": round(cfg.flops_per_frame(args.hw, args.hw) / 1e9, 3),
+                   "head_gflop_per_frame": round(hcfg.flops_per_frame_naive() / 1e9, 4)},
+        "end_to_end_tflops": round(value * flops_frame / 1e12, 2),
+    }
+    if prof:
+        gemm = [k for k in prof if k.endswith("_gemm")]
+        g_ms = sum(prof[k]["ms"] for k in gemm)
+        g_fl = sum(prof[k]["flops"] for k in gemm)
+        g_n = sum(prof[k]["launches"] for k in gemm)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_f16_kernel (all epilogues: patch/qkv/o_proj/up/down)",
+            "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "launches": g_n,
+            "share_of_timed_region": round(g_ms * 1e-3 / dt, 4),
+            "by_kernel": {k: {"avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
+                              "share": round(v["ms"] * 1e-3 / dt, 4)} for k, v in prof.items()},
+        }
+        pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                out["roofline"]["traffic"] = json.load(open(pmc)).get("gemm_f16_hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                pass
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.model, args.hw, args.cpu_frames, 8)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

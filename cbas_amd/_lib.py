@@ -43,17 +43,23 @@ SIGNATURES = {
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int, c_int]),
     "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_enc_profile": (c_int, [c_void_p, c_int]),
+    "cbas_enc_profile_read": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double),
+                                      c_int]),
     "cbas_head_weights_count": (c_int64, [C.POINTER(HeadConfigC)]),
     "cbas_head_create": (c_int, [C.POINTER(HeadConfigC), c_void_p, c_int64, c_int, C.POINTER(c_void_p)]),
     "cbas_head_destroy": (None, [c_void_p]),
     "cbas_head_forward_windows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "cbas_head_infer_f16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
+    "cbas_head_infer_f16_range": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_void_p,
+                                          c_void_p]),
     "cbas_last_error": (C.c_char_p, []),
     "cbas_abi_version": (c_int, []),
     "cbas_device_info": (c_int, [c_int, C.c_char_p, c_int, C.POINTER(c_int32), C.POINTER(c_int64)]),
 }
 
 ENC_SLOTS = 3
+PROF_CATS = ["patch_gemm", "layernorm", "qkv_gemm", "attention", "oproj_gemm", "up_gemm", "down_gemm", "other"]
 
 
 def library_path() -> str:

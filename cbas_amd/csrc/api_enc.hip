@@ -69,6 +69,11 @@ struct cbas_enc {
     hipStream_t compute = nullptr, copy = nullptr;
     Slot slots[CBAS_ENC_SLOTS];
     int64_t slot_pixels = 0;
+    // optional per-kernel-category timing (HIP events on the launch stream)
+    bool prof_on = false;
+    struct ProfRec { hipEvent_t a, b; int cat; double flops; };
+    std::vector<ProfRec> prof;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -124,6 +129,24 @@ int check_frame(cbas_enc* h, int n, int height, int width) {
     return CBAS_OK;
 }
 
+// Bracket one launch with events when profiling is on (events are created lazily and reused).
+struct ProfScope {
+    cbas_enc* h; hipStream_t st; cbas_enc::ProfRec* r = nullptr;
+    ProfScope(cbas_enc* h_, hipStream_t st_, int cat, double flops) : h(h_), st(st_) {
+        if (!h->prof_on) return;
+        if (h->prof_used == h->prof.size()) {
+            cbas_enc::ProfRec n{};
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            h->prof.push_back(n);
+        }
+        r = &h->prof[h->prof_used++];
+        r->cat = cat; r->flops = flops;
+        (void)hipEventRecord(r->a, st);
+    }
+    ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
+};
+#define PROF(cat, flops) ProfScope _prof_scope_##cat(h, st, cat, flops)
+
 // Everything after ingest: patch GEMM, L transformer blocks, final CLS norm.
 int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_scale, float* cls_f32,
                f16* cls_f16, hipStream_t st, int stop_layer, int stop_stage) {
@@ -141,44 +164,44 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     g.M = n * P; g.M_pad = (int)round_up(n * P, 128); g.N = D; g.K = patch_k;
     g.bias = h->patch_b; g.out_f32 = h->x; g.ldo = D;
     g.patches_per_frame = P; g.tokens_per_frame = T; g.n_prefix = h->NP; g.in_scale = in_scale;
-    LAUNCH_TRY(launch_gemm(EPI_PATCH, g, st));
+    { PROF(CBAS_PROF_PATCH, 2.0 * g.M * g.N * g.K); LAUNCH_TRY(launch_gemm(EPI_PATCH, g, st)); }
     if (stop_layer == 0 && stop_stage == 0) return CBAS_OK;
 
     for (int l = 0; l < h->L; ++l) {
         const LayerW& w = h->layers[l];
         auto stop = [&](int stage) { return stop_layer == l && stop_stage == stage; };
-        LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st));
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         if (stop(1)) return CBAS_OK;
 
         GemmParams q{};
         q.A = h->h16; q.W = w.wqkv; q.W_lo = h->cfg.precision ? w.wqkv_lo : nullptr;
         q.M = M; q.M_pad = M_pad; q.N = 3 * D; q.K = D; q.bias = w.qkv_b; q.out_f16 = h->qkv16; q.ldo = 3 * D;
         q.tokens_per_frame = T; q.n_prefix = h->NP; q.rope_cos = h->rope_cos; q.rope_sin = h->rope_sin; q.D = D;
-        LAUNCH_TRY(launch_gemm(EPI_QKV, q, st));
+        { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
         if (stop(2)) return CBAS_OK;
 
-        LAUNCH_TRY(launch_attention(h->qkv16, h->h16, n, T, D, h->NH, st));
+        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention(h->qkv16, h->h16, n, T, D, h->NH, st)); }
         if (stop(3)) return CBAS_OK;
 
         GemmParams o{};
         o.A = h->h16; o.W = w.wo; o.W_lo = h->cfg.precision ? w.wo_lo : nullptr;
         o.M = M; o.M_pad = M_pad; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out_f32 = h->x; o.ldo = D;
-        LAUNCH_TRY(launch_gemm(EPI_RESID, o, st));
+        { PROF(CBAS_PROF_OPROJ, 2.0 * M * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_RESID, o, st)); }
         if (stop(4)) return CBAS_OK;
 
-        LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st));
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         if (stop(5)) return CBAS_OK;
 
         GemmParams u{};
         u.A = h->h16; u.W = w.wup; u.W_lo = h->cfg.precision ? w.wup_lo : nullptr;
         u.M = M; u.M_pad = M_pad; u.N = F; u.K = D; u.bias = w.up_b; u.out_f16 = h->u16; u.ldo = F;
-        LAUNCH_TRY(launch_gemm(EPI_GELU, u, st));
+        { PROF(CBAS_PROF_UP, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_GELU, u, st)); }
         if (stop(6)) return CBAS_OK;
 
         GemmParams d{};
         d.A = h->u16; d.W = w.wdown; d.W_lo = h->cfg.precision ? w.wdown_lo : nullptr;
         d.M = M; d.M_pad = M_pad; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out_f32 = h->x; d.ldo = D;
-        LAUNCH_TRY(launch_gemm(EPI_RESID, d, st));
+        { PROF(CBAS_PROF_DOWN, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_RESID, d, st)); }
         if (stop(7)) return CBAS_OK;
     }
     if (cls_f32 || cls_f16)
@@ -219,6 +242,7 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
         if (s.ev_copied) (void)hipEventDestroy(s.ev_copied);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
+    for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->rope_cos, h->rope_sin,
                     h->A_patch, h->h16, h->qkv16, h->u16, h->x};
     for (void* b : bufs)
@@ -470,5 +494,29 @@ extern "C" int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, floa
     if (cls_f16_host) memcpy(cls_f16_host, s.out16_host, (int64_t)s.n * h->D * 2);
     if (cls_f32_host) memcpy(cls_f32_host, s.out32_host, (int64_t)s.n * h->D * 4);
     s.busy = false;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_profile(cbas_enc* h, int enable) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    h->prof_on = enable != 0;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_profile_read(cbas_enc* h, double* ms_by_cat, int64_t* launches_by_cat, double* flops_by_cat,
+                                     int reset) {
+    if (!h || !ms_by_cat || !launches_by_cat || !flops_by_cat) return cbas_fail(CBAS_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int c = 0; c < CBAS_PROF_NCAT; ++c) { ms_by_cat[c] = 0; launches_by_cat[c] = 0; flops_by_cat[c] = 0; }
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        const auto& r = h->prof[i];
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_by_cat[r.cat] += ms;
+        launches_by_cat[r.cat] += 1;
+        flops_by_cat[r.cat] += r.flops;
+    }
+    if (reset) h->prof_used = 0;
     return CBAS_OK;
 }

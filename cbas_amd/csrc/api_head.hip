@@ -207,17 +207,21 @@ extern "C" int cbas_head_forward_windows(cbas_head* h, const float* x_dev, int64
     return CBAS_OK;
 }
 
-extern "C" int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, float temperature,
-                                   float* probs_dev, float* logits_dev, void* stream) {
+extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames,
+                                         int64_t first, int64_t count, float temperature, float* probs_dev,
+                                         float* logits_dev, void* stream) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null head handle");
     if (!cls_f16_dev || n_frames <= 0) return cbas_fail(CBAS_EINVAL, "cls_f16_dev NULL or n_frames <= 0");
+    if (first < 0 || count <= 0 || first + count > n_frames)
+        return cbas_fail(CBAS_EINVAL, "range [%lld, %lld) outside the clip of %lld frames", (long long)first,
+                         (long long)(first + count), (long long)n_frames);
     if (!probs_dev && !logits_dev) return cbas_fail(CBAS_EINVAL, "no output requested");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const HeadDims& d = h->d;
     const int half = d.T / 2;
-    for (int64_t w0 = 0; w0 < n_frames; w0 += WCHUNK) {
-        const int64_t nw = n_frames - w0 < WCHUNK ? n_frames - w0 : WCHUNK;
+    for (int64_t w0 = first; w0 < first + count; w0 += WCHUNK) {
+        const int64_t nw = first + count - w0 < WCHUNK ? first + count - w0 : WCHUNK;
         // rows needed: frames [w0-half, w0+nw+half) clipped to the clip (edge replicate = clamped index)
         const int64_t r0 = w0 - half > 0 ? w0 - half : 0;
         const int64_t r1 = w0 + nw + half < n_frames ? w0 + nw + half : n_frames;
@@ -225,9 +229,15 @@ extern "C" int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, in
         LAUNCH_TRY(launch_f16_to_f32((const f16*)cls_f16_dev + r0 * d.I, h->rows32, nr * d.I, st));
         int rc = project(h, h->rows32, nr, st);
         if (rc) return rc;
-        rc = run_chunk(h, nw, 1, w0, r0, n_frames, temperature, probs_dev ? probs_dev + w0 * d.C : nullptr,
-                       logits_dev ? logits_dev + w0 * d.C : nullptr, nullptr, st);
+        const int64_t o = w0 - first;
+        rc = run_chunk(h, nw, 1, w0, r0, n_frames, temperature, probs_dev ? probs_dev + o * d.C : nullptr,
+                       logits_dev ? logits_dev + o * d.C : nullptr, nullptr, st);
         if (rc) return rc;
     }
     return CBAS_OK;
+}
+
+extern "C" int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, float temperature,
+                                   float* probs_dev, float* logits_dev, void* stream) {
+    return cbas_head_infer_f16_range(h, cls_f16_dev, n_frames, 0, n_frames, temperature, probs_dev, logits_dev, stream);
 }

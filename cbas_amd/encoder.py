@@ -168,13 +168,28 @@ class DinoEncoder:
         self._slot_n[slot] = n
 
     def wait(self, slot: int, want_f32: bool = False):
-        n = self._slot_n[slot]
+        n = getattr(self, "_slot_n", {}).pop(slot, None)
+        if n is None:
+            raise RuntimeError(f"cbas_enc_wait: slot {slot} has no submitted work")
         D = self.config.hidden_size
         o16 = np.empty((n, D), np.float16)
         o32 = np.empty((n, D), np.float32) if want_f32 else None
         _lib.check(self._lib.cbas_enc_wait(self._h, slot, o16.ctypes.data, o32.ctypes.data if want_f32 else None),
                    "cbas_enc_wait")
         return o16, o32
+
+    # -- per-kernel timing (HIP events inside the library) ------------------------------------------
+    def profile(self, enable: bool) -> None:
+        _lib.check(self._lib.cbas_enc_profile(self._h, int(bool(enable))), "cbas_enc_profile")
+
+    def profile_read(self, reset: bool = True) -> Dict[str, Dict[str, float]]:
+        n = len(_lib.PROF_CATS)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        fl = (C.c_double * n)()
+        _lib.check(self._lib.cbas_enc_profile_read(self._h, ms, cnt, fl, int(reset)), "cbas_enc_profile_read")
+        return {name: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i]}
+                for i, name in enumerate(_lib.PROF_CATS) if cnt[i] > 0}
 
     # -- bring-up taps -----------------------------------------------------------------------------
     def debug_tap(self, frames: torch.Tensor, stop_layer: int, stop_stage: int, which: int, channel: int = 1):

@@ -160,6 +160,17 @@ class ClassifierLSTMDeltas:
         return (probs, logits) if want_logits else probs
 
 
+    def infer_range_into(self, cls_f16: torch.Tensor, n_frames: int, first: int, count: int,
+                         probs_out: torch.Tensor, temperature: float = 1.0) -> None:
+        """Classify frames [first, first+count) of a clip whose first ``n_frames`` CLS rows are in
+        ``cls_f16``; writes ``probs_out[first:first+count]`` (asynchronous on the current stream)."""
+        self._ensure()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.cbas_head_infer_f16_range(
+            self._h, cls_f16.data_ptr(), n_frames, first, count, float(temperature),
+            probs_out[first:first + count].data_ptr(), None, stream), "cbas_head_infer_f16_range")
+
+
 def from_reference_module(module, device) -> ClassifierLSTMDeltas:
     """Build the MI355X head from an instantiated reference ``classifier_head.ClassifierLSTMDeltas``."""
     sd = module.state_dict()

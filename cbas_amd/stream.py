@@ -1,0 +1,73 @@
+"""Fused streaming session: encode -> fp16 CLS -> sliding-window head, without the CLS rows ever
+leaving HBM.  This is the reference's two-step pipeline (EncodeThread writes ``_cls.h5``,
+ClassificationThread reads it back: backend/workthreads.py:316-328, 488-498) collapsed into one
+pass for live inference; the numerical contract is unchanged because the head still consumes the
+CLS rows *after* their round-to-fp16 (what the file would have held).
+
+A segment of frames is classified as soon as its right-hand context (``seq_len // 2`` rows) has
+been encoded, in groups of ``classify_every`` frames so the head kernels launch with full grids.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .encoder import DinoEncoder
+from .head import ClassifierLSTMDeltas
+
+
+class ClipStream:
+    def __init__(self, encoder: DinoEncoder, head: ClassifierLSTMDeltas, capacity: int,
+                 temperature: float = 1.0, classify_every: int = 1024):
+        self.enc, self.head = encoder, head
+        self.capacity = int(capacity)
+        self.temperature = float(temperature)
+        self.classify_every = int(classify_every)
+        dev = encoder.device
+        self.cls16 = torch.empty((self.capacity, encoder.config.hidden_size), dtype=torch.float16, device=dev)
+        self.probs = torch.empty((self.capacity, head.out_features), dtype=torch.float32, device=dev)
+        self.half = head.seq_len // 2
+        self.reset()
+
+    def reset(self) -> None:
+        self.encoded = 0
+        self.classified = 0
+
+    def push_u8(self, frames: torch.Tensor, channel: int = 1) -> None:
+        """Encode one batch of uint8 frames resident in HBM ((n,H,W,3) or (n,H,W)) and classify every
+        frame whose window is now complete."""
+        n = frames.shape[0]
+        if self.encoded + n > self.capacity:
+            raise RuntimeError(f"ClipStream capacity {self.capacity} exceeded")
+        self._encode_into(frames, channel, self.cls16[self.encoded:self.encoded + n])
+        self.encoded += n
+        ready = self.encoded - self.half - self.classified          # frames with full right context
+        if ready >= self.classify_every:
+            self._classify(ready)
+
+    def _encode_into(self, frames: torch.Tensor, channel: int, out16: torch.Tensor) -> None:
+        from . import _lib
+        enc = self.enc
+        if frames.dim() == 4:
+            n, H, W, Cn = frames.shape
+            strides, off = (H * W * Cn, W * Cn, Cn), channel
+        else:
+            n, H, W = frames.shape
+            strides, off = (H * W, W, 1), 0
+        stream = torch.cuda.current_stream(enc.device).cuda_stream
+        for i in range(0, n, enc.max_batch):
+            m = min(enc.max_batch, n - i)
+            _lib.check(enc._lib.cbas_enc_forward_u8(enc._h, frames[i:i + m].data_ptr() + off, m, H, W, *strides,
+                                                    None, out16[i:i + m].data_ptr(), stream), "cbas_enc_forward_u8")
+
+    def _classify(self, count: int) -> None:
+        self.head.infer_range_into(self.cls16, self.encoded, self.classified, count, self.probs, self.temperature)
+        self.classified += count
+
+    def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Classify the tail (the clip's right edge replicates its last row) and return
+        (cls_f16 (N,D), probs (N,C)) views on the device."""
+        if self.encoded > self.classified:
+            self._classify(self.encoded - self.classified)
+        return self.cls16[:self.encoded], self.probs[:self.encoded]

@@ -174,9 +174,9 @@ def synth_head_weights(cfg: HeadConfig, seed: int = 4321) -> Dict[str, np.ndarra
         elif name.startswith("lstm.weight"):
             w = synth_uniform(seed, name, shape, -0.125, 0.125)   # torch default 1/sqrt(h)
         elif name.startswith("lin1"):
-            w = synth_normal(seed, name, shape, 0.08)
+            w = synth_normal(seed, name, shape, 0.25)             # decisive linear branch (trained heads are)
         elif name.startswith("lin2") or name.startswith("attention_head"):
-            w = synth_normal(seed, name, shape, 0.6)
+            w = synth_normal(seed, name, shape, 1.0)
         else:
             w = synth_normal(seed, name, shape, 0.08)
         out[name] = np.asarray(w, np.float32)

@@ -118,6 +118,16 @@ int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int
                               int stop_layer, int stop_stage);
 int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes);
 
+/* Per-kernel timing for benchmarks: while enabled, every kernel launch of the forward pass is
+ * bracketed by HIP events on the launch stream.  cbas_enc_profile_read synchronises the device
+ * and sums elapsed milliseconds, launch counts and algorithmic FLOPs per category (arrays of
+ * CBAS_PROF_NCAT entries); reset != 0 clears the records. */
+enum { CBAS_PROF_PATCH = 0, CBAS_PROF_LAYERNORM = 1, CBAS_PROF_QKV = 2, CBAS_PROF_ATTENTION = 3,
+       CBAS_PROF_OPROJ = 4, CBAS_PROF_UP = 5, CBAS_PROF_DOWN = 6, CBAS_PROF_NCAT = 8 };
+int cbas_enc_profile(cbas_enc* h, int enable);
+int cbas_enc_profile_read(cbas_enc* h, double* ms_by_cat, int64_t* launches_by_cat, double* flops_by_cat,
+                          int reset);
+
 /* ---- classifier head ---------------------------------------------------------------------- */
 
 /* Mirrors ClassifierLSTMDeltas.__init__ (backend/classifier_head.py:62-64). */
@@ -158,6 +168,14 @@ int cbas_head_forward_windows(cbas_head* h, const float* x_dev, int64_t n_window
  * (replicate edge padding, backend/cbas.py:512-525). */
 int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, float temperature,
                         float* probs_dev, float* logits_dev, void* stream);
+
+/* Same for the frames [first, first+count) of a clip of n_frames rows: outputs are count x C.
+ * Windows still clamp to [0, n_frames), so a clip can be classified in segments while it is being
+ * encoded (pass the number of rows encoded so far; a segment is final once first+count+seq_len/2
+ * rows exist, or at the end of the clip). */
+int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, int64_t first,
+                              int64_t count, float temperature, float* probs_dev, float* logits_dev,
+                              void* stream);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 

@@ -1,0 +1,186 @@
+"""CPU-side checks: synthetic generators, blob packing, the C-ABI surface of the built library (no
+compute calls), _cls.h5 / CSV formats, configuration parsing, error behaviour without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cbas_amd import config as Cfg, weights as W, synth, h5io, _lib
+from cbas_amd import build as B
+
+
+def test_generators_are_deterministic_and_scaled():
+    a = W.synth_normal(1, "x", (1000, 64), 0.02)
+    b = W.synth_normal(1, "x", (1000, 64), 0.02)
+    assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert abs(a.std() - 0.02) < 5e-4 and abs(a.mean()) < 5e-4
+    assert not np.array_equal(a, W.synth_normal(2, "x", (1000, 64), 0.02))
+    assert not np.array_equal(a, W.synth_normal(1, "y", (1000, 64), 0.02))
+    u = W.synth_uniform(1, "u", (10000,), -0.5, 0.5)
+    assert u.min() >= -0.5 and u.max() < 0.5 and abs(u.mean()) < 0.02
+    f = synth.noise_frames(0, 3, 32, 48)
+    assert f.shape == (3, 32, 48, 3) and f.dtype == np.uint8
+    assert np.array_equal(f[1:], synth.noise_frames(0, 2, 32, 48, first=1))       # per-frame streams
+    c = synth.cage_frames(1, 2, 32, 32)
+    assert np.array_equal(c[:, :, :, 2], 255 - c[:, :, :, 1])
+
+
+def test_known_answer_hash():
+    # pins the counter-based generator itself (a change here would silently invalidate every golden)
+    a = W.synth_normal(1234, "embeddings.cls_token", (4,), 1.0)
+    h = W._hash_stream(1234, "embeddings.cls_token", 2)
+    assert h.dtype == np.uint64
+    assert np.array_equal(a, W.synth_normal(1234, "embeddings.cls_token", (4,), 1.0))
+    assert W._fnv1a64("") == 0xCBF29CE484222325 and W._fnv1a64("a") == 0xAF63DC4C8601EC8C
+
+
+@pytest.mark.parametrize("name,params_m", [("vits16", 21.60), ("vitb16", 85.66), ("vitl16", 303.1)])
+def test_encoder_param_counts_match_survey(name, params_m):
+    cfg = Cfg.NAMED_VIT[name]
+    n = sum(int(np.prod(s)) for k, s in W.encoder_param_shapes(cfg).items() if not k.endswith("mask_token"))
+    assert abs(n / 1e6 - params_m) < 0.05, n
+
+
+@pytest.mark.parametrize("name,hw,gflop", [("vits16", 224, 9.40), ("vitb16", 224, 35.86), ("vitb16", 256, 47.15),
+                                           ("vitl16", 518, 727.2)])
+def test_flops_per_frame_match_survey(name, hw, gflop):
+    assert abs(Cfg.NAMED_VIT[name].flops_per_frame(hw, hw) / 1e9 - gflop) / gflop < 2e-3
+
+
+def test_head_param_count_and_flops():
+    hc = Cfg.HeadConfig()
+    n = sum(int(np.prod(s)) if len(s) else 1 for s in W.head_param_shapes(hc).values())
+    assert n == 567701
+    assert abs(hc.flops_per_frame_naive() / 1e9 - 0.0347) < 5e-4
+
+
+def test_library_exports_every_declared_symbol():
+    """include/cbas_mi355x.h <-> libcbas_mi355x.so <-> the ctypes table, without touching a GPU."""
+    path = B.build_library()
+    lib = C.CDLL(path)
+    header = open(os.path.join(os.path.dirname(B.HERE), "include", "cbas_mi355x.h")).read()
+    declared = set(re.findall(r"\b(cbas_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cbas_enc_config", "cbas_head_config"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.cbas_abi_version() == 1
+
+
+def test_weight_counts_agree_between_host_and_library():
+    from cbas_amd.encoder import pack_encoder_weights
+    from cbas_amd.head import pack_head_weights
+    lib = _lib.load()
+    cfg = Cfg.VIT_TINY
+    blob = pack_encoder_weights(cfg, W.synth_encoder_weights(cfg, 1))
+    cc = _lib.EncConfig(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                        cfg.num_register_tokens, 16, 1e-5, 100.0, 8, 64, 64, 0)
+    assert lib.cbas_enc_weights_count(C.byref(cc)) == blob.shape[0]
+    for h in (64, 128):
+        hc = Cfg.HeadConfig(lstm_hidden_size=h, out_features=7)
+        hb = pack_head_weights(hc, W.synth_head_weights(hc, 2))
+        hcc = _lib.HeadConfigC(hc.in_features, hc.out_features, hc.seq_len, hc.bottleneck_dim, hc.lin0_dim,
+                               hc.lstm_hidden_size, hc.center_window_size, hc.ema_alpha)
+        assert lib.cbas_head_weights_count(C.byref(hcc)) == hb.shape[0]
+
+
+def test_create_rejects_bad_arguments_without_gpu():
+    lib = _lib.load()
+    cc = _lib.EncConfig(100, 400, 2, 2, 4, 16, 1e-5, 100.0, 8, 64, 64, 0)      # hidden_size not /128
+    h = C.c_void_p()
+    dummy = np.zeros(4, np.float32)
+    rc = lib.cbas_enc_create(C.byref(cc), dummy.ctypes.data, 4, 0, C.byref(h))
+    assert rc == -1 and b"hidden_size" in lib.cbas_last_error()
+    assert lib.cbas_enc_forward_u8(None, None, 1, 16, 16, 0, 0, 0, None, None, None) == -1
+    assert lib.cbas_head_infer_f16(None, None, 1, 1.0, None, None, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cbas_amd.encoder import DinoEncoder
+    cfg = Cfg.VIT_TINY
+    with pytest.raises(RuntimeError):
+        DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1), "cpu")
+    from cbas_amd.head import ClassifierLSTMDeltas
+    m = ClassifierLSTMDeltas(768, 9)
+    m.load_state_dict(W.synth_head_weights(Cfg.HeadConfig(), 1))
+    m.to("cpu")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 31, 768))
+
+
+def test_head_state_dict_validation():
+    from cbas_amd.head import pack_head_weights
+    hc = Cfg.HeadConfig()
+    w = W.synth_head_weights(hc, 1)
+    del w["lin2.bias"]
+    with pytest.raises(KeyError):
+        pack_head_weights(hc, w)
+    assert W.infer_head_config(W.synth_head_weights(Cfg.HeadConfig(lstm_hidden_size=128, out_features=4), 1)) \
+        .lstm_hidden_size == 128
+
+
+def test_cls_h5_roundtrip_and_layout(tmp_path):
+    p = str(tmp_path / "v_cls.h5")
+    rows = synth.cls_walk(1, 700, 768)
+    with h5io.ClsWriter(p, 768, {"encoder_model_identifier": "facebook/dinov3-vitb16-pretrain-lvd1689m",
+                                 "schema_version": "1.0"}) as w:
+        w.append(rows[:512]); w.flush(); w.append(rows[512:].astype(np.float32)); w.flush()
+    with h5io.ClsReader(p) as r:
+        assert r.shape == (700, 768) and r.itemsize == 2
+        assert r.attrs == {"encoder_model_identifier": "facebook/dinov3-vitb16-pretrain-lvd1689m",
+                           "schema_version": "1.0"}
+        assert np.array_equal(r.read(0, 700), rows)
+        assert np.array_equal(r.read(690, 9999), rows[690:])
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        import subprocess
+        txt = subprocess.run([h5dump, "-H", "-p", p], capture_output=True, text=True).stdout
+        assert "16-bit little-endian floating-point" in txt
+        assert "( 700, 768 ) / ( H5S_UNLIMITED, 768 )" in txt and "CHUNKED ( 8192, 768 )" in txt
+        assert "H5T_VARIABLE" in txt and "H5T_CSET_UTF8" in txt
+    with h5io.ClsWriter(str(tmp_path / "e_cls.h5"), 384) as w:
+        pass
+    with h5io.ClsReader(str(tmp_path / "e_cls.h5")) as r:
+        assert r.shape == (0, 384) and r.attrs == {}
+
+
+def test_csv_text_matches_pandas_golden(golden_dir, tmp_path):
+    from cbas_amd.pipeline import format_probs_csv, write_probs_csv
+    g = np.load(os.path.join(golden_dir, "infer_file.npz"))
+    names = ["eating", "drinking", "rearing", "climbing", "digging", "nesting", "resting", "grooming", "exploring"]
+    for n in (1, 10, 31, 64, 40):
+        want = bytes(g[f"csv_{n}"]).decode()
+        assert format_probs_csv(g[f"probs_{n}"], names) == want
+        p = str(tmp_path / f"o{n}.csv")
+        write_probs_csv(p, g[f"probs_{n}"], names)
+        assert open(p).read() == want
+    assert format_probs_csv(np.array([[1e-5, 0.5]], np.float32), ["a,b", 'q"']).splitlines()[0] == '"a,b","q"""'
+    assert format_probs_csv(np.array([[1.2e-5, 1.0]], np.float32), ["a", "b"]).splitlines()[1] == "1.2e-05,1.0"
+
+
+def test_checkpoint_dir_roundtrip(tmp_path):
+    cfg = Cfg.VIT_TINY
+    w = W.synth_encoder_weights(cfg, 5)
+    W.save_encoder_checkpoint(str(tmp_path / "ck"), cfg, w)
+    cfg2, w2 = W.load_encoder_checkpoint(Cfg.find_checkpoint_dir(str(tmp_path / "ck")))
+    assert cfg2 == cfg and all(np.array_equal(w[k], w2[k]) for k in w)
+    with pytest.raises(FileNotFoundError):
+        Cfg.find_checkpoint_dir("facebook/definitely-not-cached")
+    with pytest.raises(NotImplementedError):
+        Cfg.ViTConfig(use_gated_mlp=True).validate()
+
+
+def test_frame_sources(tmp_path):
+    from cbas_amd import pipeline as P
+    fr = synth.cage_frames(2, 5, 32, 32)
+    np.save(str(tmp_path / "clip.npy"), fr)
+    src = P.open_video(str(tmp_path / "clip.npy"))
+    assert len(src) == 5 and np.array_equal(src.get_batch(range(1, 4)), fr[1:4])
+    with pytest.raises(RuntimeError):
+        P.open_video(str(tmp_path / "clip.mp4"))          # decord absent, no reader registered
