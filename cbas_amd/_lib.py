@@ -72,6 +72,9 @@ def load(build_if_missing: bool = True):
     with _lock:
         if _lib is not None:
             return _lib
+        # torch ships its own libamdhip64; import it FIRST so this library binds to the same HIP
+        # runtime (two runtimes in one process do not see the GPU: "no ROCm-capable device")
+        import torch  # noqa: F401
         path = _build.LIB_PATH
         if not os.path.exists(path):
             if not build_if_missing:
