@@ -4,6 +4,7 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <algorithm>
 
 #include "api_common.h"
 #include "kernels.h"
@@ -518,5 +519,96 @@ extern "C" int cbas_enc_profile_read(cbas_enc* h, double* ms_by_cat, int64_t* la
         flops_by_cat[r.cat] += r.flops;
     }
     if (reset) h->prof_used = 0;
+    return CBAS_OK;
+}
+
+// ---- bring-up: stand-alone GEMM timing / bit-exactness harness ---------------------------------
+namespace {
+__global__ void fill_random_f16(f16* p, int64_t n, uint32_t seed, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = (f16)(((float)(x & 0xFFFF) / 32768.0f - 1.0f) * scale);
+}
+__global__ void checksum_u16(const uint16_t* p, int64_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += (unsigned long long)p[i] * (unsigned long long)((i % 1021) + 1);
+    atomicAdd(out, s);
+}
+}  // namespace
+
+extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
+                                     unsigned long long* checksum_out) {
+    // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100
+    const bool want_stamps = tile >= 1000;   // 1000 + tile: also print the block timeline statistics
+    tile %= 1000;
+    const bool resid = tile >= 100;
+    if (resid) tile -= 100;
+    if (M <= 0 || N % 128 || K % 64 || iters <= 0) return cbas_fail(CBAS_EINVAL, "bad GEMM bench shape");
+    const int64_t M_pad = round_up(M, 256);
+    f16 *A = nullptr, *Wt = nullptr, *out = nullptr;
+    float* bias = nullptr;
+    unsigned long long* cs = nullptr;
+    HIP_TRY(hipMalloc(&A, M_pad * (int64_t)K * 2));
+    HIP_TRY(hipMalloc(&Wt, (int64_t)N * K * 2));
+    HIP_TRY(hipMalloc(&out, M_pad * (int64_t)N * 2));
+    HIP_TRY(hipMalloc(&bias, (int64_t)N * 4));
+    HIP_TRY(hipMalloc(&cs, 8));
+    HIP_TRY(hipMemset(bias, 0, (int64_t)N * 4));
+    HIP_TRY(hipMemset(out, 0, M_pad * (int64_t)N * 2));
+    HIP_TRY(hipMemset(cs, 0, 8));
+    hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)((M_pad * K + 255) / 256)), dim3(256), 0, 0, A, M_pad * K, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)(((int64_t)N * K + 255) / 256)), dim3(256), 0, 0, Wt, (int64_t)N * K, 2u, 0.05f);
+    GemmParams p{};
+    p.tile = tile; p.A = A; p.W = Wt; p.M = M; p.M_pad = (int)M_pad; p.N = N; p.K = K; p.bias = bias; p.out_f16 = out; p.ldo = N;
+    float* x32 = nullptr;
+    if (resid) {
+        HIP_TRY(hipMalloc(&x32, M_pad * (int64_t)N * 4));
+        HIP_TRY(hipMemset(x32, 0, M_pad * (int64_t)N * 4));
+        p.out_f32 = x32; p.lambda = bias;      // lambda = 0: x stays 0, timing only
+    }
+    const GemmEpilogue epi = resid ? EPI_RESID : EPI_GELU;
+    int rc = launch_gemm(epi, p, 0);
+    if (rc) return cbas_fail(CBAS_EINVAL, "launch_gemm failed for tile %d (rc=%d)", tile, rc);
+    HIP_TRY(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_gemm(epi, p, 0);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    if (want_stamps) {
+        const int nblk = 16384;
+        unsigned long long* st = nullptr;
+        HIP_TRY(hipMalloc(&st, (size_t)nblk * 32));
+        HIP_TRY(hipMemset(st, 0, (size_t)nblk * 32));
+        p.stamps = st;
+        launch_gemm(epi, p, 0);
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs((size_t)nblk * 4);
+        HIP_TRY(hipMemcpy(hs.data(), st, (size_t)nblk * 32, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0; double pro = 0, loop = 0, epi_c = 0; int n = 0;
+        for (int b = 0; b < nblk; ++b) {
+            if (!hs[4 * b + 3]) continue;
+            t0 = std::min(t0, hs[4 * b]); t1 = std::max(t1, hs[4 * b + 3]);
+            pro += (double)(hs[4 * b + 1] - hs[4 * b]); loop += (double)(hs[4 * b + 2] - hs[4 * b + 1]);
+            epi_c += (double)(hs[4 * b + 3] - hs[4 * b + 2]); ++n;
+        }
+        printf("  stamps: %d blocks, kernel span %.0f ticks; per block avg prologue %.0f, loop %.0f, epilogue %.0f ticks (100 MHz ticks)\n",
+               n, (double)(t1 - t0), pro / n, loop / n, epi_c / n);
+        fflush(stdout);
+        p.stamps = nullptr;
+        hipFree(st);
+    }
+    hipLaunchKernelGGL(checksum_u16, dim3(1024), dim3(256), 0, 0, (const uint16_t*)out, (int64_t)M * N, cs);
+    if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, cs, 8, hipMemcpyDeviceToHost));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32);
     return CBAS_OK;
 }

@@ -1,0 +1,195 @@
+// Fused GEMM epilogues shared by the fp16 GEMM kernels.  The kernels issue their MFMAs with the
+// operands swapped, so a lane holds, for ONE output row m, 4 consecutive columns in each of the 4
+// accumulator tiles that make up a 64-column group (= one attention head for the QKV projection):
+//     v[j][e]  <->  C[m][head_col0 + j*16 + (lane>>4)*4 + e],   j = 0..3, e = 0..3
+// Reference arithmetic: bias adds of nn.Linear, RoPE [tf]:238-268 (rotate_half :203-207),
+// LayerScale :342-343 + residual :432-443, exact-erf GELU :356, conv bias / token scatter :82-89.
+#pragma once
+#include "kernels.h"
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, int head_col0, int lane,
+                                                  const f32x4 (&acc)[4]) {
+    const int ncol = head_col0 + (lane >> 4) * 4;     // + j*16
+    if (EPI == EPI_PATCH) {
+        const int b = m / p.patches_per_frame;
+        const int orow = b * p.tokens_per_frame + p.n_prefix + (m - b * p.patches_per_frame);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 v = acc[j] * p.in_scale + bv;
+            *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)orow * p.ldo + n) = v;
+        }
+    } else if (EPI == EPI_QKV) {
+        const int sec = head_col0 / p.D;               // 0 q, 1 k, 2 v: uniform over the 64-column group
+        const int t = m % p.tokens_per_frame;
+        const bool rope = (sec < 2) && (t >= p.n_prefix);
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + ncol + j * 16);
+        if (rope) {
+            const size_t ro = (size_t)(t - p.n_prefix) * 64 + (lane >> 4) * 4;
+            f32x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
+                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
+                // rotate_half(x)[d] = -x[d+32] (d < 32), x[d-32] (d >= 32)
+                o[j] = (j < 2) ? (v[j] * c - v[j + 2] * s) : (v[j] * c + v[j - 2] * s);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = o[j];
+        }
+        const float qs = (sec == 0) ? 0.125f : 1.0f;   // head_dim^-0.5, exact power of two
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 w = v[j] * qs;
+            const f16x4 hv = {(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
+            *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldo + ncol + j * 16) = hv;
+        }
+    } else if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(p.lambda + n);
+            float* xp = p.out_f32 + (size_t)m * p.ldo + n;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp);
+            *reinterpret_cast<f32x4*>(xp) = (acc[j] + bv) * lv + xv;
+        }
+    } else {  // EPI_GELU
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 w = acc[j] + bv;
+            const f16x4 hv = {(f16)gelu_fast(w[0]), (f16)gelu_fast(w[1]), (f16)gelu_fast(w[2]), (f16)gelu_fast(w[3])};
+            *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldo + n) = hv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coalesced tile epilogue.  The accumulator layout above gives each lane 4-column fragments at a
+// row stride of ldo: a wave store touches 16 rows x 32-64 bytes (quarter/half cache lines) and the
+// fp32 residual update reads AND writes x that way; measured with s_memtime stamps this took
+// 13-17k cycles per 128x128 tile against a 20k-cycle main loop.  Here each wave bounces its 64-wide
+// tile through a private LDS scratch (the staging buffers are idle after the K loop) so that every
+// global access is whole 128-byte (fp16) / 256-byte (fp32) row segments.
+//   scratch: 8 KiB per wave, 16-byte aligned, wave-private (in-order LDS => no barrier needed).
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_base, int head_col0, int lane,
+                                                   const f32x4 (&acc)[TM][4], char* scratch) {
+    const int li = lane & 15, g = lane >> 4;
+    if (EPI == EPI_PATCH) {                      // small GEMM with a row scatter: keep the direct form
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = row_base + i * 16 + li;
+            if (m < p.M) gemm_epilogue_row<EPI_PATCH>(p, m, head_col0, lane, acc[i]);
+        }
+    } else if (EPI == EPI_RESID) {
+        // The raw accumulators are transposed 16 rows at a time (two 4 KiB scratch halves, alternating);
+        // in the transposed layout a lane owns ONE 4-column chunk for every row, so bias and lambda are
+        // a single vector each, and x is read/written in whole 256-byte row segments.  The x rows are
+        // prefetched two slabs ahead: the read-modify-write is otherwise a serial latency chain.
+        const f32x4 bvt = *reinterpret_cast<const f32x4*>(p.bias + head_col0 + li * 4);
+        const f32x4 lvt = *reinterpret_cast<const f32x4*>(p.lambda + head_col0 + li * 4);
+        f32x4 xs[2][4];
+        auto load_x = [&](int i, f32x4 (&dst)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int m = row_base + i * 16 + it * 4 + g;
+                m = m < p.M ? m : p.M - 1;                             // clamp: never read past the valid rows
+                dst[it] = *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)m * p.ldo + head_col0 + li * 4);
+            }
+        };
+        load_x(0, xs[0]);
+        if (TM > 1) load_x(1, xs[1]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            char* sc = scratch + (i & 1) * 4096;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = (4 * j + g) ^ li;                        // 16-byte chunk swizzle by row
+                *reinterpret_cast<f32x4*>(sc + li * 256 + q * 16) = acc[i][j];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 4 + g;                              // row within the 16-row slab
+                const f32x4 y = *reinterpret_cast<const f32x4*>(sc + r * 256 + ((li ^ r) << 4));
+                const int m = row_base + i * 16 + r;
+                if (m < p.M)
+                    *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + head_col0 + li * 4) =
+                        (y + bvt) * lvt + xs[i & 1][it];
+            }
+            if (i + 2 < TM) load_x(i + 2, xs[i & 1]);
+            asm volatile("" ::: "memory");
+        }
+    } else {                                     // EPI_QKV / EPI_GELU: fp16 out, whole 64x(TM*16) tile at once
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + head_col0 + j * 16 + g * 4);
+        const int sec = (EPI == EPI_QKV) ? head_col0 / p.D : 2;
+        const float qs = (sec == 0) ? 0.125f : 1.0f;
+#pragma unroll
+        for (int half = 0; half < TM / 4; ++half) {                    // 64 rows per pass (8 KiB of scratch)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = half * 4 + ii;
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
+                if (EPI == EPI_QKV) {
+                    const int m = row_base + i * 16 + li;
+                    const int t = m % p.tokens_per_frame;
+                    if (sec < 2 && t >= p.n_prefix) {
+                        const size_t ro = (size_t)(t - p.n_prefix) * 64 + g * 4;
+                        f32x4 o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
+                            const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
+                            o[j] = (j < 2) ? (v[j] * c - v[j + 2] * s) : (v[j] * c + v[j - 2] * s);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = o[j] * qs;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] * qs;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = f32x4{gelu_fast(v[j][0]), gelu_fast(v[j][1]), gelu_fast(v[j][2]), gelu_fast(v[j][3])};
+                }
+                const int rl = ii * 16 + li;                            // row within the 64-row pass
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = (4 * j + g) ^ ((rl & 7) << 1);        // 8-byte granule swizzle, pairs stay adjacent
+                    const f16x4 hv = {(f16)v[j][0], (f16)v[j][1], (f16)v[j][2], (f16)v[j][3]};
+                    *reinterpret_cast<f16x4*>(scratch + rl * 128 + q * 8) = hv;
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + (lane >> 3), c = lane & 7;      // 8 rows x 128 bytes per wave store
+                const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
+                const int m = row_base + half * 64 + r;
+                if (m < p.M) *reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8) = hv;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+__device__ __forceinline__ int gemm_xcd_remap(int orig, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of
+    // logical tile ids so neighbouring tiles (same A row-panel) hit one L2.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}

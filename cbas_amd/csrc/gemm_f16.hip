@@ -16,32 +16,30 @@
 // Reference arithmetic replaced: nn.Linear calls at [tf] modeling_dinov3_vit.py:307-309 (q/k/v),
 // :331 (o_proj), :356-357 (MLP), conv patch embedding :82, RoPE :238-268, LayerScale :342-343,
 // residual adds :432-443.
-#include "kernels.h"
+#include <stdlib.h>
+#include "gemm_epilogue.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
+constexpr int BK = 64;
 
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of
-    // logical tile ids so neighbouring tiles (same A row-panel) hit one L2.  Bijective for any nwg.
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (orig >> 3);
-}
-
-// Stage a 128-row x 64-half tile: 16 pieces of 1 KiB, 4 per wave.  LDS image: row r at r*128 B,
-// 16-B slot s of row r holds global chunk s ^ ((r>>1)&7)  (swizzle applied on the SOURCE address;
-// the LDS-DMA destination is lane-linear).
-__device__ __forceinline__ void stage_tile(const f16* __restrict__ g, int ld, int row0, int k0,
+// Stage a ROWS-row x 64-half tile as ROWS/8 pieces of 1 KiB, ROWS/8/NW per wave.  LDS image: row r
+// at r*128 B, 16-B slot s of row r holds global chunk s ^ ((r>>1)&7)  (swizzle applied on the
+// SOURCE address; the LDS-DMA destination is lane-linear).  Rows past `last_row` are clamped (their
+// products land in output rows/columns that are never stored).
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_tile(const f16* __restrict__ g, int ld, int row0, int last_row, int k0,
                                            char* lds_tile, int wave, int lane) {
+    constexpr int PER = ROWS / 8 / NW;
+    static_assert(PER * 8 * NW == ROWS, "tile rows must split evenly over the waves");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
+    for (int i = 0; i < PER; ++i) {
+        const int piece = wave * PER + i;
         const int r = piece * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const f16* src = g + (size_t)(row0 + r) * ld + k0 + chunk * 8;
+        int row = row0 + r;
+        row = row < last_row ? row : last_row;
+        const f16* src = g + (size_t)row * ld + k0 + chunk * 8;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
     }
 }
@@ -51,17 +49,22 @@ __device__ __forceinline__ f16x8 read_frag(const char* lds_tile, int row, int ch
     return *reinterpret_cast<const f16x8*>(lds_tile + off);
 }
 
-template <int EPI, int NSPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
+// Workgroup tile = (64*WM) x (64*WN), one 64x64 sub-tile per wave.  The larger tiles exist because
+// at 128x128 the kernel stages 1 byte per 64 FLOP from L2 / Infinity Cache into LDS, which caps it
+// near the measured L2->LDS rate; 256x256 halves that traffic.
+template <int EPI, int NSPLIT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BUF_BYTES = TILE_BYTES * (1 + NSPLIT);
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES * NSPLIT;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
     const int tiles_n = p.N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = gemm_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk = p.K / BK;
@@ -74,21 +77,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * BUF_BYTES;
-        stage_tile(p.A, p.K, row0, kt * BK, base, wave, lane);
-        stage_tile(p.W, p.K, col0, kt * BK, base + TILE_BYTES, wave, lane);
-        if (NSPLIT == 2) stage_tile(p.W_lo, p.K, col0, kt * BK, base + 2 * TILE_BYTES, wave, lane);
+        stage_tile<BM, NW>(p.A, p.K, row0, p.M_pad - 1, kt * BK, base, wave, lane);
+        stage_tile<BN, NW>(p.W, p.K, col0, p.N - 1, kt * BK, base + A_BYTES, wave, lane);
+        if (NSPLIT == 2) stage_tile<BN, NW>(p.W_lo, p.K, col0, p.N - 1, kt * BK, base + A_BYTES + B_BYTES, wave, lane);
     };
 
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
 
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* At = smem + cur * BUF_BYTES;
-        const char* Wt = At + TILE_BYTES;
+        const char* Wt = At + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 a[4], b[4];
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
             if (NSPLIT == 2) {
-                const char* Wl = Wt + TILE_BYTES;
+                const char* Wl = Wt + B_BYTES;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[j] = read_frag(Wl, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
 #pragma unroll
@@ -116,99 +122,78 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns row m (per i) and columns n0..n0+3 (per j) -------------------------
-    const int ncol = col0 + wc * 64 + (lane >> 4) * 4;     // + j*16
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = row0 + wr * 64 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        if (EPI == EPI_PATCH) {
-            const int b = m / p.patches_per_frame;
-            const int orow = b * p.tokens_per_frame + p.n_prefix + (m - b * p.patches_per_frame);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = ncol + j * 16;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-                f32x4 v = acc[i][j] * p.in_scale + bv;
-                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)orow * p.ldo + n) = v;
-            }
-        } else if (EPI == EPI_QKV) {
-            const int sec = (col0 + wc * 64) / p.D;        // 0 q, 1 k, 2 v: wave-uniform (64 | D)
-            const int t = m % p.tokens_per_frame;
-            const bool rope = (sec < 2) && (t >= p.n_prefix);
-            f32x4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v[j] = acc[i][j] + *reinterpret_cast<const f32x4*>(p.bias + ncol + j * 16);
-            if (rope) {
-                const size_t ro = (size_t)(t - p.n_prefix) * 64 + (lane >> 4) * 4;
-                f32x4 o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
-                    // rotate_half(x)[d] = -x[d+32] (d < 32), x[d-32] (d >= 32)
-                    o[j] = (j < 2) ? (v[j] * c - v[j + 2] * s) : (v[j] * c + v[j - 2] * s);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = o[j];
-            }
-            const float qs = (sec == 0) ? 0.125f : 1.0f;   // head_dim^-0.5, exact power of two
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 w = v[j] * qs;
-                f16x4 hv = {(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
-                *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldo + ncol + j * 16) = hv;
-            }
-        } else if (EPI == EPI_RESID) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = ncol + j * 16;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-                const f32x4 lv = *reinterpret_cast<const f32x4*>(p.lambda + n);
-                float* xp = p.out_f32 + (size_t)m * p.ldo + n;
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp);
-                *reinterpret_cast<f32x4*>(xp) = (acc[i][j] + bv) * lv + xv;
-            }
-        } else {  // EPI_GELU
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = ncol + j * 16;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-                const f32x4 w = acc[i][j] + bv;
-                f16x4 hv = {(f16)gelu_erf(w[0]), (f16)gelu_erf(w[1]), (f16)gelu_erf(w[2]), (f16)gelu_erf(w[3])};
-                *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldo + n) = hv;
-            }
-        }
+    if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+    // ---- epilogue: lane owns row m (per i) and 4 consecutive columns in each of the 4 n-tiles ---
+    gemm_epilogue_tile<EPI, 4>(p, row0 + wr * 64, col0 + wc * 64, lane, acc, smem + wave * 8192);
+    if (p.stamps && tid == 0) {       // diagnostic builds only: block timeline (start, prologue, loop, end)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
     }
 }
 
-template <int EPI, int NSPLIT>
+template <int EPI, int NSPLIT, int WM, int WN>
 int launch_one(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds = 2 * TILE_BYTES * (1 + NSPLIT);
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int lds = 2 * (BM * 128 + BN * 128 * NSPLIT);
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;   // per-instantiation; idempotent, racing callers set the same value
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<EPI, NSPLIT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<EPI, NSPLIT, WM, WN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
-    const int grid = (p.M_pad / BM) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_f16_kernel<EPI, NSPLIT>), dim3(grid), dim3(256), lds, stream, p);
+    if (p.N % BN) return -1;
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, NSPLIT, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int EPI>
+int launch_epi(const GemmParams& p, int tile, hipStream_t stream) {
+    const bool split = p.W_lo != nullptr;
+    if (split) {      // the hi+lo weight tiles need 50 % more LDS: 128x128 and 256x128 only
+        if (tile == GEMM_TILE_256x128 || tile == GEMM_TILE_256x256) return launch_one<EPI, 2, 4, 2>(p, stream);
+        return launch_one<EPI, 2, 2, 2>(p, stream);
+    }
+    switch (tile) {
+        case GEMM_TILE_256x256: return launch_one<EPI, 1, 4, 4>(p, stream);
+        case GEMM_TILE_256x128: return launch_one<EPI, 1, 4, 2>(p, stream);
+        case GEMM_TILE_128x256: return launch_one<EPI, 1, 2, 4>(p, stream);
+        default: return launch_one<EPI, 1, 2, 2>(p, stream);
+    }
+}
+
+// Tile choice: estimated time = rounds over the CU slots x cost of one tile-round.  The larger tiles
+// halve the L2->LDS traffic but quantise worse; costs are relative per-round times measured on
+// MI355X with scripts/gemm_tiles.py.
+int pick_tile(const GemmParams& p) {
+    static const int forced = [] { const char* e = getenv("CBAS_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (forced) return forced;
+    if (p.tile) return p.tile;
+    int best = GEMM_TILE_128x128;
+    return best;
 }
 
 }  // namespace
 
-int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream) {
-    if (p.M_pad % BM || p.N % BN || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
-    if (epi == EPI_QKV && (p.D % 64 || p.N != 3 * p.D)) return -1;
-    const bool split = p.W_lo != nullptr;
+static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
+    if (tile >= GEMM_TILE_RING_FIRST) return launch_gemm_ring(epi, p, tile, stream);
     switch (epi) {
-        case EPI_PATCH: return split ? launch_one<EPI_PATCH, 2>(p, stream) : launch_one<EPI_PATCH, 1>(p, stream);
-        case EPI_QKV:   return split ? launch_one<EPI_QKV, 2>(p, stream)   : launch_one<EPI_QKV, 1>(p, stream);
-        case EPI_RESID: return split ? launch_one<EPI_RESID, 2>(p, stream) : launch_one<EPI_RESID, 1>(p, stream);
-        case EPI_GELU:  return split ? launch_one<EPI_GELU, 2>(p, stream)  : launch_one<EPI_GELU, 1>(p, stream);
+        case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
+        case EPI_QKV:   return launch_epi<EPI_QKV>(p, tile, stream);
+        case EPI_RESID: return launch_epi<EPI_RESID>(p, tile, stream);
+        case EPI_GELU:  return launch_epi<EPI_GELU>(p, tile, stream);
     }
     return -1;
+}
+
+int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream) {
+    if (p.N % 128 || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
+    if (epi == EPI_QKV && (p.D % 64 || p.N != 3 * p.D)) return -1;
+    const int tile = pick_tile(p);
+    int rc = dispatch_gemm(epi, p, tile, stream);
+    if (rc == -1 && tile != GEMM_TILE_128x128) rc = dispatch_gemm(epi, p, GEMM_TILE_128x128, stream);   // shape not tileable that way
+    return rc;
 }

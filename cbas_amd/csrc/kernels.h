@@ -13,12 +13,19 @@ enum GemmEpilogue {
     EPI_GELU  = 3,   // u[m][n] = gelu_erf(acc + bias[n])                             (fp16 out)
 };
 
+enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2, GEMM_TILE_128x256 = 3,
+                GEMM_TILE_256x256 = 4,
+                GEMM_TILE_RING_FIRST = 5,       // gemm_f16_ring.hip: 4-deep LDS ring, counted vmcnt
+                GEMM_TILE_RING_256x256_W16 = 5, GEMM_TILE_RING_256x256_W8 = 6 };
+
 struct GemmParams {
+    int tile;            // GemmTile (0 = pick by shape)
+    unsigned long long* stamps;   // bring-up only: per-block s_memtime stamps [grid][4], or nullptr
     const f16* A;        // [M_pad][K]
     const f16* W;        // [N][K]  (hi part when split)
     const f16* W_lo;     // [N][K]  residual W - fp16(W) as fp16, or nullptr
     int M;               // valid rows (stores are skipped for rows >= M)
-    int M_pad;           // rows the grid covers, multiple of 128
+    int M_pad;           // rows allocated in A (loads of rows >= M_pad are clamped)
     int N;               // multiple of 128
     int K;               // multiple of 64
     const float* bias;   // [N]
@@ -38,6 +45,7 @@ struct GemmParams {
 };
 
 int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);
+int launch_gemm_ring(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // ViT element-wise / attention kernels

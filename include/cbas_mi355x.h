@@ -118,6 +118,12 @@ int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int
                               int stop_layer, int stop_stage);
 int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes);
 
+/* Bring-up: time the fp16 GEMM kernel alone on random operands (GELU epilogue, M x N x K,
+ * tile: 0 auto, 1 128x128, 2 256x128, 3 128x256, 4 256x256, 5+ experimental variants) and return a
+ * position-weighted checksum of the fp16 output, so tile variants can be compared bit for bit. */
+int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
+                          unsigned long long* checksum_out);
+
 /* Per-kernel timing for benchmarks: while enabled, every kernel launch of the forward pass is
  * bracketed by HIP events on the launch stream.  cbas_enc_profile_read synchronises the device
  * and sums elapsed milliseconds, launch counts and algorithmic FLOPs per category (arrays of
