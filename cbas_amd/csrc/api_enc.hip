@@ -70,6 +70,11 @@ struct cbas_enc {
     hipStream_t compute = nullptr, copy = nullptr;
     Slot slots[CBAS_ENC_SLOTS];
     int64_t slot_pixels = 0;
+    // lane 0 = the buffers above; lane 1 = a second set for the two-stream split of a batch
+    struct Lane { f16 *A_patch, *h16, *qkv16, *u16; float* x; hipStream_t stream; hipEvent_t done; };
+    Lane lanes[2] = {};
+    hipEvent_t ev_fork = nullptr;
+    bool dual_lanes = false;
     // optional per-kernel-category timing (HIP events on the launch stream)
     bool prof_on = false;
     struct ProfRec { hipEvent_t a, b; int cat; double flops; };
@@ -211,6 +216,22 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     return CBAS_OK;
 }
 
+int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
+                   int64_t row_stride, int64_t pixel_stride, float* cls_f32, f16* cls_f16, hipStream_t st,
+                   int stop_layer, int stop_stage) {
+    const int T = (height / 16) * (width / 16) + h->NP;
+    LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
+                                h->x, h->prefix, h->NP, h->D, T, st));
+    return run_blocks(h, n, height, width, 256, 1.0f / 255.0f, cls_f32, cls_f16, st, stop_layer, stop_stage);
+}
+
+// Point the handle's workspace pointers at lane `l` (kernel arguments are captured at launch, so the
+// host-side switch is safe while the other lane's kernels are still running).
+void use_lane(cbas_enc* h, int l) {
+    const cbas_enc::Lane& L = h->lanes[l];
+    h->A_patch = L.A_patch; h->x = L.x; h->h16 = L.h16; h->qkv16 = L.qkv16; h->u16 = L.u16;
+}
+
 int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
                int64_t row_stride, int64_t pixel_stride, float* cls_f32, f16* cls_f16, hipStream_t st,
                int stop_layer, int stop_stage) {
@@ -218,10 +239,31 @@ int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int wi
     if (rc) return rc;
     if (!frames_dev) return cbas_fail(CBAS_EINVAL, "frames_dev is NULL");
     HIP_TRY(hipSetDevice(h->device));
-    const int T = (height / 16) * (width / 16) + h->NP;
-    LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
-                                h->x, h->prefix, h->NP, h->D, T, st));
-    return run_blocks(h, n, height, width, 256, 1.0f / 255.0f, cls_f32, cls_f16, st, stop_layer, stop_stage);
+    const bool split = h->dual_lanes && stop_layer < 0 && n >= 16;
+    if (!split)
+        return forward_u8_one(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32,
+                              cls_f16, st, stop_layer, stop_stage);
+    // Two half-batches on two internal streams: one half's kernel tails, LayerNorm, attention and
+    // epilogues overlap the other half's GEMM main loops.  Results are bit-identical to the
+    // single-lane order (rows are independent).
+    rc = ensure_rope(h, height / 16, width / 16, st);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_fork, st));
+    const int n0 = (n + 1) / 2;
+    for (int l = 0; l < 2; ++l) {
+        const int off = l ? n0 : 0, cnt = l ? n - n0 : n0;
+        hipStream_t ls = h->lanes[l].stream;
+        HIP_TRY(hipStreamWaitEvent(ls, h->ev_fork, 0));
+        use_lane(h, l);
+        rc = forward_u8_one(h, frames_dev + (int64_t)off * frame_stride, cnt, height, width, frame_stride, row_stride,
+                            pixel_stride, cls_f32 ? cls_f32 + (int64_t)off * h->D : nullptr,
+                            cls_f16 ? cls_f16 + (int64_t)off * h->D : nullptr, ls, -1, -1);
+        if (rc) { use_lane(h, 0); return rc; }
+        HIP_TRY(hipEventRecord(h->lanes[l].done, ls));
+        HIP_TRY(hipStreamWaitEvent(st, h->lanes[l].done, 0));
+    }
+    use_lane(h, 0);
+    return CBAS_OK;
 }
 
 }  // namespace
@@ -244,6 +286,17 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (h->lanes[0].x) { h->A_patch = h->lanes[0].A_patch; h->x = h->lanes[0].x; h->h16 = h->lanes[0].h16;
+                         h->qkv16 = h->lanes[0].qkv16; h->u16 = h->lanes[0].u16; }
+    for (int l = 0; l < 2; ++l) {
+        if (h->lanes[l].stream) { (void)hipStreamSynchronize(h->lanes[l].stream); (void)hipStreamDestroy(h->lanes[l].stream); }
+        if (h->lanes[l].done) (void)hipEventDestroy(h->lanes[l].done);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    {
+        void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16};
+        for (void* b : b1) if (b) (void)hipFree(b);
+    }
     void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->rope_cos, h->rope_sin,
                     h->A_patch, h->h16, h->qkv16, h->u16, h->x};
     for (void* b : bufs)
@@ -377,6 +430,35 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->u16, 0, h->rows_cap * F * sizeof(f16), st));
+    // second lane (half-batch overlap on two streams).  Measured on MI355X it LOSES 15-40 % (blocks
+    // with 64-128 KiB of LDS cannot co-reside, the two kernels only evict each other's operands), so
+    // it is off unless CBAS_DUAL_LANES=1 asks for the experiment.
+    {
+        const char* e = getenv("CBAS_DUAL_LANES");
+        h->dual_lanes = (e && e[0] == '1');
+        cbas_enc::Lane& L0 = h->lanes[0];
+        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16;
+        if (h->dual_lanes) {
+            cbas_enc::Lane& L1 = h->lanes[1];
+            const int64_t rows1 = round_up(((int64_t)c.max_batch / 2 + 1) * Tmax, 128);
+            const int64_t prow1 = round_up(((int64_t)c.max_batch / 2 + 1) * Pmax, 128);
+            CREATE_TRY(hipMalloc(&L1.A_patch, prow1 * 512 * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.x, rows1 * D * sizeof(float)));
+            CREATE_TRY(hipMalloc(&L1.h16, rows1 * D * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.qkv16, rows1 * 3 * D * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.u16, rows1 * F * sizeof(f16)));
+            CREATE_TRY(hipMemsetAsync(L1.A_patch, 0, prow1 * 512 * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.x, 0, rows1 * D * sizeof(float), st));
+            CREATE_TRY(hipMemsetAsync(L1.h16, 0, rows1 * D * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.qkv16, 0, rows1 * 3 * D * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.u16, 0, rows1 * F * sizeof(f16), st));
+            for (int l = 0; l < 2; ++l) {
+                CREATE_TRY(hipStreamCreateWithFlags(&h->lanes[l].stream, hipStreamNonBlocking));
+                CREATE_TRY(hipEventCreateWithFlags(&h->lanes[l].done, hipEventDisableTiming));
+            }
+            CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        }
+    }
 
     // host-streaming slots
     h->slot_pixels = (int64_t)c.max_batch * c.max_height * c.max_width;

@@ -30,11 +30,11 @@ constexpr int BK = 64;
 template <int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const f16* __restrict__ g, int ld, int row0, int last_row, int k0,
                                            char* lds_tile, int wave, int lane) {
-    constexpr int PER = ROWS / 8 / NW;
-    static_assert(PER * 8 * NW == ROWS, "tile rows must split evenly over the waves");
+    constexpr int PIECES = ROWS / 8, PER = (PIECES + NW - 1) / NW;     // uneven split allowed (12 waves)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int piece = wave * PER + i;
+        const int piece = wave + i * NW;
+        if (PIECES % NW != 0 && piece >= PIECES) break;                // wave-uniform
         const int r = piece * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         int row = row0 + r;
@@ -161,6 +161,7 @@ int launch_epi(const GemmParams& p, int tile, hipStream_t stream) {
         case GEMM_TILE_256x256: return launch_one<EPI, 1, 4, 4>(p, stream);
         case GEMM_TILE_256x128: return launch_one<EPI, 1, 4, 2>(p, stream);
         case GEMM_TILE_128x256: return launch_one<EPI, 1, 2, 4>(p, stream);
+        case GEMM_TILE_192x256: return launch_one<EPI, 1, 3, 4>(p, stream);
         default: return launch_one<EPI, 1, 2, 2>(p, stream);
     }
 }
@@ -172,14 +173,26 @@ int pick_tile(const GemmParams& p) {
     static const int forced = [] { const char* e = getenv("CBAS_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
     if (p.tile) return p.tile;
-    int best = GEMM_TILE_128x128;
-    return best;
+    // Measured with scripts/gemm_tiles.py at M = 12 864 (64 frames x 201 tokens), ViT-B shapes: the
+    // 256x256 tile (16 waves, 1 workgroup per CU, 83 % MFMA-efficient main loop) wins on every
+    // projection once there are enough tiles to occupy the chip; below that the 128x128 tile
+    // (2 workgroups per CU, 4x the tiles) does.
+    if (!p.W_lo && p.N % 256 == 0) {
+        const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+        const long t192 = (long)((p.M + 191) / 192) * (p.N / 256);
+        if (t256 >= 120) {
+            // one workgroup per CU for both: time ~ rounds over the 256 CUs x tile rows
+            const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+            return c192 < c256 ? GEMM_TILE_192x256 : GEMM_TILE_256x256;
+        }
+    }
+    return GEMM_TILE_128x128;
 }
 
 }  // namespace
 
 static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
-    if (tile >= GEMM_TILE_RING_FIRST) return launch_gemm_ring(epi, p, tile, stream);
+    if (tile == GEMM_TILE_RING_256x256_W16 || tile == GEMM_TILE_RING_256x256_W8) return launch_gemm_ring(epi, p, tile, stream);
     switch (epi) {
         case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
         case EPI_QKV:   return launch_epi<EPI_QKV>(p, tile, stream);

@@ -16,7 +16,8 @@ enum GemmEpilogue {
 enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2, GEMM_TILE_128x256 = 3,
                 GEMM_TILE_256x256 = 4,
                 GEMM_TILE_RING_FIRST = 5,       // gemm_f16_ring.hip: 4-deep LDS ring, counted vmcnt
-                GEMM_TILE_RING_256x256_W16 = 5, GEMM_TILE_RING_256x256_W8 = 6 };
+                GEMM_TILE_RING_256x256_W16 = 5, GEMM_TILE_RING_256x256_W8 = 6,
+                GEMM_TILE_192x256 = 7 };
 
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)

@@ -6,6 +6,7 @@
 //                 the patch weights by pack_patch_weight), [tf]:82-83 (Conv2d k=s=16 as im2col), :86-89 (prefix tokens)
 //   layernorm     [tf]:404,410 (norm1/norm2), :540 (final norm; only the CLS row is needed, cbas.py:677)
 //   attention     [tf]:210-234 (softmax(q k^T * 64^-0.5) v), heads split/merge :311-313,:330
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace {
@@ -172,10 +173,10 @@ __device__ __forceinline__ int v_off(int row, int col) {   // col in halves
 }
 
 template <int NKT>
-__global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
-                                                        int T, int D, int n_heads) {
+__global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
+                                                           int T, int D, int n_heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWS = NKT * 16;
+    constexpr int ROWS = NKT * 16, NG = NKT / 2;
     char* Ks = smem;
     char* Vs = smem + ROWS * 128;
 
@@ -185,6 +186,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     const f16* qbase = qkv + (size_t)b * T * ld + hd * 64;
     const f16* kbase = qbase + D;
     const f16* vbase = qbase + 2 * D;
+    const int g = lane >> 4, li = lane & 15;
+    const int nqt = (T + 15) >> 4;
+
+    auto load_q = [&](int qt, f16x8 (&qf)[2]) {
+        const int q = qt * 16 + li;
+        const int qrow = q < T ? q : T - 1;
+        qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
+        qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
+    };
+    // Q of this wave's first tile is fetched before the K/V staging so its latency hides under it
+    f16x8 qf[2] = {}, qn[2] = {};
+    int qt = wave;
+    if (qt < nqt) load_q(qt, qf);
 
     for (int idx = tid; idx < ROWS * 8; idx += blockDim.x) {
         const int r = idx >> 3, c = idx & 7;
@@ -198,59 +212,65 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     }
     __syncthreads();
 
-    const int g = lane >> 4, li = lane & 15;
-    const int nqt = (T + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += nwaves) {
+    for (; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + li;
-        const int qrow = q < T ? q : T - 1;
-        f16x8 qf[2];
-        qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
-        qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
+        if (qt + nwaves < nqt) load_q(qt + nwaves, qn);          // next tile's Q under this tile's math
 
+        // ---- S^T = K Q^T, two key tiles (4 fragment reads, 4 MFMAs) per group; the scheduling
+        // barriers keep the compiler from hoisting all 2*NKT fragment reads (4 VGPRs each) up front
         f32x4 s[NKT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int grp = 0; grp < NG; ++grp) {
+            f16x8 kf[4];
 #pragma unroll
-            for (int dd = 0; dd < 2; ++dd) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + k_off(kt * 16 + li, dd * 4 + g));
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dd], s[kt], 0, 0, 0);
+            for (int u = 0; u < 4; ++u)
+                kf[u] = *reinterpret_cast<const f16x8*>(Ks + k_off((2 * grp + (u >> 1)) * 16 + li, (u & 1) * 4 + g));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * u], qf[0], acc, 0, 0, 0);
+                s[2 * grp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * u + 1], qf[1], acc, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // s[kt][r] = S[q][key = kt*16 + 4g + r]   (q already carries the 1/8 scale)
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt * 16 + 16 > T) {                                  // only the tail tile(s) hold padding keys
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
-                const float v = key < T ? s[kt][r] : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
             }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m2 = mx * 1.4426950408889634f;
         float sum = 0.f;
+        f16x8 pf[NG];                                                // P^T packed as the B operand of P.V
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int grp = 0; grp < NG; ++grp) {
+            f32x4 e0, e1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f((s[kt][r] - mx) * 1.4426950408889634f);
-                s[kt][r] = e;
-                sum += e;
+                e0[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp][r], 1.4426950408889634f, -m2));
+                e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1][r], 1.4426950408889634f, -m2));
             }
+            sum += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
+            pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
 
+        // ---- O^T = V^T P^T: V through the hardware-transposing LDS read, 8 reads + 4 MFMAs per group
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s2 = 0; s2 < NKT / 2; ++s2) {
-            const f32x4 p0 = s[2 * s2], p1 = s[2 * s2 + 1];
-            const f16x8 pf = {(f16)p0[0], (f16)p0[1], (f16)p0[2], (f16)p0[3],
-                              (f16)p1[0], (f16)p1[1], (f16)p1[2], (f16)p1[3]};
+        for (int s2 = 0; s2 < NG; ++s2) {
             const int krow = 32 * s2 + 4 * g + (li >> 2);
+            f16x8 vf[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int col = 16 * dt + 4 * (li & 3);
@@ -260,8 +280,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
                     (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow + 16, col)));
                 union { struct { s16x4 a, b; } s; f16x8 v; } u;
                 u.s.a = lo; u.s.b = hi;
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf, o[dt], 0, 0, 0);
+                vf[dt] = u.v;
             }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt], pf[s2], o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q < T) {
             const float inv = 1.0f / sum;
@@ -273,6 +296,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
                 *reinterpret_cast<f16x4*>(orow + 16 * dt) = hv;
             }
         }
+        qf[0] = qn[0]; qf[1] = qn[1];
     }
 }
 
@@ -286,7 +310,10 @@ int launch_attention_t(const f16* qkv, f16* out, int n, int T, int D, int n_head
             return -2;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<NKT>), dim3(n * n_heads), dim3(256), lds, stream, qkv, out, T, D, n_heads);
+    // at most 8 waves (a 1024-thread bound caps the kernel at 128 VGPRs and it spills); the fewest waves that keep
+    // every wave equally loaded: T = 201 -> 13 tiles -> 7 waves x 2, T = 261 -> 17 tiles -> 6 waves x 3
+    const int nqt = (T + 15) / 16, rounds = (nqt + 7) / 8, nwaves = (nqt + rounds - 1) / rounds;
+    hipLaunchKernelGGL((attention_kernel<NKT>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, out, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
