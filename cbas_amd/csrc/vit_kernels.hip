@@ -300,6 +300,131 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for long token sequences (T > 288, e.g. ViT-L/16 at 518x518: T = 1029), where
+// K and V of one head (2 x 132 KB) no longer fit the LDS: one workgroup = 8 waves = 128 queries of
+// one (frame, head); keys stream through a double-buffered 64-key LDS block with an online softmax
+// (running max m, partial sums l, O rescaled by exp2((m_old - m_new) log2e) per block).  Same
+// S^T = K Q^T / P^T-as-B-operand / transposing-read-of-V layout as the resident kernel: a lane's
+// accumulators all belong to ONE query, so the rescale is a per-lane scalar.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
+                                                                  int T, int D, int n_heads) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];    // [buf][K|V][64 keys][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / n_heads, hd = blockIdx.x - b * n_heads;
+    const size_t ld = (size_t)3 * D;
+    const f16* qbase = qkv + (size_t)b * T * ld + hd * 64;
+    const f16* kbase = qbase + D;
+    const f16* vbase = qbase + 2 * D;
+    const int g = lane >> 4, li = lane & 15;
+    const int nkb = (T + 63) >> 6;
+    const int q = (blockIdx.y * 8 + wave) * 16 + li;
+    const int qrow = q < T ? q : T - 1;
+    f16x8 qf[2];
+    qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
+    qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
+
+    const int sr = tid >> 3, sc = tid & 7;                     // staging: one 16-byte chunk of K and of V per thread
+    auto load_blk = [&](int kb, f16x8& kv, f16x8& vv) {
+        const int r = kb * 64 + sr;
+        kv = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        vv = kv;
+        if (r < T) {
+            kv = *reinterpret_cast<const f16x8*>(kbase + (size_t)r * ld + sc * 8);
+            vv = *reinterpret_cast<const f16x8*>(vbase + (size_t)r * ld + sc * 8);
+        }
+    };
+    auto store_blk = [&](int buf, const f16x8& kv, const f16x8& vv) {
+        char* Kb = smem + buf * 16384;
+        *reinterpret_cast<f16x8*>(Kb + k_off(sr, sc)) = kv;
+        *reinterpret_cast<f16x8*>(Kb + 8192 + v_off(sr, sc * 8)) = vv;
+    };
+    f16x8 kv, vv;
+    load_blk(0, kv, vv);
+    store_blk(0, kv, vv);
+    __syncthreads();
+
+    float m = -INFINITY, l = 0.f;                              // m: shared by the 4 lane groups of a query; l: per-lane partial
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + 1 < nkb) load_blk(kb + 1, kv, vv);
+        const char* Ks = smem + (kb & 1) * 16384;
+        const char* Vs = Ks + 8192;
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(Ks + k_off(kt * 16 + li, g)), qf[0], acc, 0, 0, 0);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(Ks + k_off(kt * 16 + li, 4 + g)), qf[1], acc, 0, 0, 0);
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kb * 64 + kt * 16 + 16 > T) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb * 64 + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
+            }
+            bm = fmaxf(bm, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float m_new = fmaxf(m, bm);                      // finite: block 0 always holds key 0
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * 1.4426950408889634f);
+        const float m2 = m_new * 1.4426950408889634f;
+        m = m_new;
+        float bs = 0.f;
+        f16x8 pf[2];
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            f32x4 e0, e1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e0[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp][r], 1.4426950408889634f, -m2));
+                e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1][r], 1.4426950408889634f, -m2));
+            }
+            bs += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
+            pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
+        }
+        l = l * alpha + bs;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int krow = 32 * s2 + 4 * g + (li >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = 16 * dt + 4 * (li & 3);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow, col)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow + 16, col)));
+                union { struct { s16x4 a, b; } s; f16x8 v; } u;
+                u.s.a = lo; u.s.b = hi;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[s2], o[dt], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < nkb) store_blk((kb + 1) & 1, kv, vv);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q < T) {
+        const float inv = 1.0f / l;
+        f16* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 w = o[dt] * inv;
+            f16x4 hv = {(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
+            *reinterpret_cast<f16x4*>(orow + 16 * dt) = hv;
+        }
+    }
+}
+
 template <int NKT>
 int launch_attention_t(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
     constexpr int lds = NKT * 16 * 128 * 2;
@@ -408,7 +533,10 @@ int launch_attention(const f16* qkv, f16* out, int n, int T, int D, int n_heads,
     if (nkt <= 6) return launch_attention_t<6>(qkv, out, n, T, D, n_heads, stream);
     if (nkt <= 14) return launch_attention_t<14>(qkv, out, n, T, D, n_heads, stream);
     if (nkt <= 18) return launch_attention_t<18>(qkv, out, n, T, D, n_heads, stream);
-    return -1;   // T > 288: needs the streaming (online-softmax) variant, not built yet
+    // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
+    const int nqb = ((T + 15) / 16 + 7) / 8;
+    hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, out, T, D, n_heads);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t stream) {

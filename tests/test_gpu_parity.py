@@ -116,7 +116,8 @@ def test_error_codes(tiny):
 
 @pytest.mark.parametrize("name,cfgname,hw,prec", [("vits16_224", "vits16", 224, 0), ("vitb16_224", "vitb16", 224, 0),
                                                   ("vitb16_224_noise", "vitb16", 224, 0), ("vitb16_256", "vitb16", 256, 0),
-                                                  ("vitl16_224", "vitl16", 224, 0), ("vitb16_224", "vitb16", 224, 1)])
+                                                  ("vitl16_224", "vitl16", 224, 0), ("vitb16_224", "vitb16", 224, 1),
+                                                  ("vitl16_518", "vitl16", 518, 0)])   # T = 1029: streaming attention
 def test_cls_goldens(golden_dir, name, cfgname, hw, prec):
     from cbas_amd.encoder import DinoEncoder
     g = load(golden_dir, name)
