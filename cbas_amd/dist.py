@@ -46,9 +46,9 @@ def gather_rows(local: Sequence[torch.Tensor], dst: int = 0) -> Optional[List[Li
     all with the same trailing dim and dtype across ranks).  Returns on ``dst`` a list over ranks
     of lists of tensors (on the same device as the inputs); ``None`` elsewhere.
 
-    Two collectives: an all_gather of the row counts, then one padded gather of the concatenated
-    rows (7 concurrent point-to-point transfers into rank 0 on the xGMI mesh; payloads are a few
-    tens of MB per 30-minute clip)."""
+    Collectives: all_gathers of the clip counts / row counts / dtype code, then one padded all_gather of
+    the concatenated rows (payloads are a few tens of MB per 30-minute clip; every
+    GPU has its own xGMI link to every peer, so the exchange is link-parallel)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
@@ -82,8 +82,10 @@ def gather_rows(local: Sequence[torch.Tensor], dst: int = 0) -> Optional[List[Li
     if len(local):
         cat = torch.cat(list(local), dim=0)
         buf[:cat.shape[0]] = cat
-    recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, recv, dst=dst)
+    # all_gather rather than gather: the most widely supported collective on every backend (RCCL
+    # gather is emulated with send/recv anyway); the payload is a few tens of MB per clip
+    recv = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(recv, buf)
     if rank != dst:
         return None
     out: List[List[torch.Tensor]] = []
@@ -113,7 +115,10 @@ def interleave_by_clip(per_rank: List[List[torch.Tensor]], n_clips: int) -> List
 
 def barrier() -> None:
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:
