@@ -146,14 +146,19 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                     const int m = row_base + i * 16 + li;
                     const int t = m % p.tokens_per_frame;
                     if (sec < 2 && t >= p.n_prefix) {
+                        // the table is angles.tile(2) ([tf]:190): columns d and d+32 hold the same value,
+                        // so two loads per table serve all four 16-column groups
                         const size_t ro = (size_t)(t - p.n_prefix) * 64 + g * 4;
+                        f32x4 cs[2], sn[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            cs[j] = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
+                            sn[j] = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
+                        }
                         f32x4 o[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
-                            const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
-                            o[j] = (j < 2) ? (v[j] * c - v[j + 2] * s) : (v[j] * c + v[j - 2] * s);
-                        }
+                        for (int j = 0; j < 4; ++j)
+                            o[j] = (j < 2) ? (v[j] * cs[j] - v[j + 2] * sn[j]) : (v[j] * cs[j - 2] + v[j - 2] * sn[j - 2]);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = o[j] * qs;
                     } else {

@@ -65,7 +65,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
 
     const int tiles_n = p.N / BN;
     const int bid = gemm_xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    int tm, tn;
+    if (p.group_m <= 1) {
+        tm = bid / tiles_n; tn = bid - tm * tiles_n;
+    } else {
+        // grouped raster: GM row-panels share each W column tile while it is hot in the XCD's L2
+        const int tiles_m = gridDim.x / tiles_n;
+        const int gsz = p.group_m * tiles_n, gid = bid / gsz, first = gid * p.group_m;
+        const int gm = tiles_m - first < p.group_m ? tiles_m - first : p.group_m;
+        const int in = bid - gid * gsz;
+        tm = first + in % gm; tn = in / gm;
+    }
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk = p.K / BK;
 
@@ -192,7 +202,8 @@ int pick_tile(const GemmParams& p) {
 }  // namespace
 
 static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
-    if (tile == GEMM_TILE_RING_256x256_W16 || tile == GEMM_TILE_RING_256x256_W8) return launch_gemm_ring(epi, p, tile, stream);
+    if (tile == GEMM_TILE_RING_256x256_W16 || tile == GEMM_TILE_RING_256x256_W8 || (tile >= 8 && tile <= 11))
+        return launch_gemm_ring(epi, p, tile, stream);
     switch (epi) {
         case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
         case EPI_QKV:   return launch_epi<EPI_QKV>(p, tile, stream);
@@ -202,7 +213,10 @@ static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStr
     return -1;
 }
 
-int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream) {
+int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    static const int gm_env = [] { const char* e = getenv("CBAS_GEMM_GM"); return e ? atoi(e) : 0; }();
+    if (!p.group_m) p.group_m = gm_env > 0 ? gm_env : 1;
     if (p.N % 128 || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
     if (epi == EPI_QKV && (p.D % 64 || p.N != 3 * p.D)) return -1;
     const int tile = pick_tile(p);

@@ -18,7 +18,6 @@
 namespace {
 
 constexpr int RBK = 32;          // halves of K per ring slot
-constexpr int RING = 4;
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ (((row >> 2) & 1) * 3); }
 
@@ -27,9 +26,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// WM x WN waves; each wave owns (TM*16) rows x 64 columns.
-template <int EPI, int WM, int WN, int TM>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f16_ring_kernel(GemmParams p) {
+// WM x WN waves; each wave owns (TM*16) rows x 64 columns; RING LDS slots, prefetch distance RING-1.
+template <int EPI, int WM, int WN, int TM, int RING, int WPE>
+__global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_f16_ring_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
     constexpr int BM = WM * TM * 16, BN = WN * 64;
@@ -71,18 +70,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
         src[i] = (isA ? p.A : p.W) + (size_t)grow * p.K + chunk * 8;
         dst[i] = (isA ? 0 : A_BYTES) + piece * 1024;
     }
+    constexpr int DIST = RING - 1;
     auto stage = [&](int kt) {
-        char* base = smem + (kt & (RING - 1)) * SLOT_BYTES;
+        char* base = smem + (kt % RING) * SLOT_BYTES;
 #pragma unroll
         for (int i = 0; i < PER; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + kt * RBK), LDS_PTR(base + dst[i]), 16, 0, 0);
     };
 
-    // prologue: three K-tiles in flight, retire the first
-    stage(0);
-    if (nk > 1) stage(1);
-    if (nk > 2) stage(2);
-    if (nk > 2) wait_vmcnt<2 * PER>(); else if (nk > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    // prologue: DIST K-tiles in flight, retire the first
+    auto wait_leave = [&](int tiles_in_flight) {             // wave-uniform; counts must be immediates
+        if (tiles_in_flight >= 2 && DIST >= 3) wait_vmcnt<2 * PER>();
+        else if (tiles_in_flight >= 1 && DIST >= 2) wait_vmcnt<PER>();
+        else wait_vmcnt<0>();
+    };
+#pragma unroll
+    for (int t = 0; t < DIST; ++t)
+        if (t < nk) stage(t);
+    wait_leave((nk < DIST ? nk : DIST) - 1);
     __builtin_amdgcn_s_barrier();
 
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -99,8 +104,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
     }
 
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 3 < nk) stage(kt + 3);
-        const char* slot = smem + (kt & (RING - 1)) * SLOT_BYTES;
+        if (kt + DIST < nk) stage(kt + DIST);
+        const char* slot = smem + (kt % RING) * SLOT_BYTES;
         f16x8 a[TM], b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(slot + b_off[j]);
@@ -112,37 +117,43 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
         // retire K-tile kt+1 (read in the NEXT step, one barrier after this wait); leave the rest in flight
-        if (kt + 3 < nk) wait_vmcnt<2 * PER>();
-        else if (kt + 2 < nk) wait_vmcnt<PER>();
-        else wait_vmcnt<0>();
+        {
+            const int last = kt + DIST < nk - 1 ? kt + DIST : nk - 1;   // newest K-tile staged so far
+            wait_leave(last - (kt + 1));
+        }
         __builtin_amdgcn_s_barrier();
     }
 
     gemm_epilogue_tile<EPI, TM>(p, row0 + wr * TM * 16, col0 + wc * 64, lane, acc, smem + wave * 8192);
 }
 
-template <int EPI, int WM, int WN, int TM>
+template <int EPI, int WM, int WN, int TM, int RING, int WPE>
 int launch_ring(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
-    constexpr int lds = RING * (BM + BN) * 64;
+    constexpr int ring_bytes = RING * (BM + BN) * 64, scratch_bytes = WM * WN * 8192;   // epilogue: 8 KiB per wave
+    constexpr int lds = ring_bytes > scratch_bytes ? ring_bytes : scratch_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ring_kernel<EPI, WM, WN, TM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ring_kernel<EPI, WM, WN, TM, RING, WPE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
     if (p.N % BN || p.K % RBK || p.W_lo) return -1;
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_f16_ring_kernel<EPI, WM, WN, TM>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16_ring_kernel<EPI, WM, WN, TM, RING, WPE>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <int EPI>
 int launch_ring_epi(const GemmParams& p, int tile, hipStream_t stream) {
     switch (tile) {
-        case GEMM_TILE_RING_256x256_W16: return launch_ring<EPI, 4, 4, 4>(p, stream);
-        case GEMM_TILE_RING_256x256_W8:  return launch_ring<EPI, 2, 4, 8>(p, stream);
+        case GEMM_TILE_RING_256x256_W16: return launch_ring<EPI, 4, 4, 4, 4, 4>(p, stream);
+        case GEMM_TILE_RING_256x256_W8:  return launch_ring<EPI, 2, 4, 8, 4, 2>(p, stream);
+        case 8:  return launch_ring<EPI, 2, 4, 4, 2, 4>(p, stream);    // 128x256, 2 slots (48 KB): 2-3 WGs/CU
+        case 9:  return launch_ring<EPI, 2, 4, 4, 3, 4>(p, stream);    // 128x256, 3 slots (72 KB): 2 WGs/CU
+        case 10: return launch_ring<EPI, 4, 2, 4, 3, 4>(p, stream);    // 256x128, 3 slots (72 KB): 2 WGs/CU
+        case 11: return launch_ring<EPI, 2, 2, 4, 4, 4>(p, stream);    // 128x128, 4 slots (64 KB): 2 WGs/CU, 4 waves
         default: return -1;
     }
 }

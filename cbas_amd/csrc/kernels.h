@@ -21,6 +21,7 @@ enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2
 
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)
+    int group_m;         // raster: row-panels per group (0/1 = N-fastest order)
     unsigned long long* stamps;   // bring-up only: per-block s_memtime stamps [grid][4], or nullptr
     const f16* A;        // [M_pad][K]
     const f16* W;        // [N][K]  (hi part when split)
