@@ -40,10 +40,40 @@ def layer_norm(x: np.ndarray, w: np.ndarray, b: np.ndarray, eps: float) -> np.nd
     return (xc / np.sqrt(var + F32(eps))) * w + b
 
 
+_POOL = None
+
+
+def _erf_mt(x: np.ndarray) -> np.ndarray:
+    """scipy's erf ufunc is single-threaded (and releases the GIL): split large arrays over the cores
+    the process may use, so the CPU baseline is not dominated by one core evaluating erf."""
+    global _POOL
+    if x.size < (1 << 16):
+        return _erf(x)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, int(os.environ.get("CBAS_CPU_BASELINE_THREADS", "32"))))
+    if n == 1:
+        return _erf(x)
+    if _POOL is None or _POOL._max_workers != n:
+        _POOL = ThreadPoolExecutor(max_workers=n)
+    flat = np.ascontiguousarray(x).reshape(-1)
+    out = np.empty_like(flat)
+    bounds = np.linspace(0, flat.size, n + 1).astype(np.int64)
+
+    def work(i):
+        _erf(flat[bounds[i]:bounds[i + 1]], out=out[bounds[i]:bounds[i + 1]])
+    list(_POOL.map(work, range(n)))
+    return out.reshape(x.shape)
+
+
 def gelu_erf(x: np.ndarray) -> np.ndarray:
     """ACT2FN['gelu'] = exact erf GELU ([tf]:354, hidden_act default 'gelu')."""
-    x64 = x.astype(np.float64)
-    return (0.5 * x64 * (1.0 + _erf(x64 / math.sqrt(2.0)))).astype(F32)
+    x = x.astype(F32, copy=False)            # float32 erf, as torch's CPU GELU kernel computes it
+    return (F32(0.5) * x * (F32(1.0) + _erf_mt(x * F32(1.0 / math.sqrt(2.0))))).astype(F32, copy=False)
 
 
 def rope_cos_sin(n_h: int, n_w: int, head_dim: int, theta: float):
