@@ -21,7 +21,8 @@ class EncConfig(C.Structure):
     _fields_ = [("hidden_size", c_int32), ("intermediate_size", c_int32), ("num_layers", c_int32),
                 ("num_heads", c_int32), ("num_register_tokens", c_int32), ("patch_size", c_int32),
                 ("layer_norm_eps", c_float), ("rope_theta", c_float), ("max_batch", c_int32),
-                ("max_height", c_int32), ("max_width", c_int32), ("precision", c_int32)]
+                ("max_height", c_int32), ("max_width", c_int32), ("precision", c_int32),
+                ("use_rope", c_int32), ("pos_embed_grid", c_int32)]
 
 
 class HeadConfigC(C.Structure):

@@ -32,6 +32,13 @@ class ViTConfig:
     use_gated_mlp: bool = False
     hidden_act: str = "gelu"
     num_channels: int = 3
+    # encoder family: "dinov3_vit" (RoPE, no additive position embedding) or "dinov2_with_registers"
+    # (learned position embedding on a pos_embed_grid x pos_embed_grid lattice, bicubically
+    # interpolated to the frame's patch grid; no RoPE; key bias) - CBAS's default project encoder
+    # (reference backend/cbas.py:1030-1033)
+    model_type: str = "dinov3_vit"
+    use_rope: bool = True
+    pos_embed_grid: int = 0
 
     @property
     def head_dim(self) -> int:
@@ -62,29 +69,43 @@ class ViTConfig:
             raise NotImplementedError(f"hidden_act={self.hidden_act!r}; only exact-erf 'gelu' is implemented")
         if self.head_dim != 64:
             raise NotImplementedError("head_dim must be 64 (all DINOv3 ViT-S/B/L checkpoints)")
-        if self.patch_size != 16:
-            raise NotImplementedError("patch_size must be 16")
-        if self.key_bias:
-            raise NotImplementedError("key_bias=True is not implemented (DINOv3 checkpoints use False)")
+        if self.patch_size not in (14, 16):
+            raise NotImplementedError("patch_size must be 14 (DINOv2) or 16 (DINOv3)")
+        if self.model_type not in ("dinov3_vit", "dinov2_with_registers"):
+            raise NotImplementedError(f"model_type={self.model_type!r} is not built")
+        if self.use_rope == (self.pos_embed_grid > 0):
+            raise NotImplementedError("exactly one of RoPE / learned position embedding is expected")
         if not (self.query_bias and self.value_bias and self.proj_bias and self.mlp_bias):
             raise NotImplementedError("query/value/proj/mlp biases are expected (DINOv3 defaults)")
 
     def to_json(self) -> str:
         d = asdict(self)
-        d["model_type"] = "dinov3_vit"
+        if self.model_type == "dinov2_with_registers":      # write the fields HF's config class reads back
+            d.update(mlp_ratio=self.intermediate_size // self.hidden_size, qkv_bias=self.query_bias,
+                     use_swiglu_ffn=self.use_gated_mlp)
         return json.dumps(d, indent=2)
 
     @classmethod
     def from_json_file(cls, path: str) -> "ViTConfig":
         with open(path, "r") as f:
             raw = json.load(f)
-        if raw.get("model_type", "dinov3_vit") != "dinov3_vit":
-            raise NotImplementedError(
-                f"model_type={raw.get('model_type')!r}: only DINOv3 ViT encoders are built so far")
+        mt = raw.get("model_type", "dinov3_vit")
+        if mt not in ("dinov3_vit", "dinov2_with_registers"):
+            raise NotImplementedError(f"model_type={mt!r}: only DINOv3 ViT and DINOv2-with-registers encoders are built")
         known = {k: raw[k] for k in cls.__dataclass_fields__ if k in raw}
         for key in ("patch_size", "image_size"):
             if isinstance(known.get(key), (list, tuple)):
                 known[key] = int(known[key][0])
+        if mt == "dinov2_with_registers":
+            # HF Dinov2WithRegistersConfig (configuration_dinov2_with_registers.py): mlp_ratio, qkv_bias, use_swiglu_ffn
+            hs = int(raw.get("hidden_size", 768))
+            qkv_bias = bool(raw.get("qkv_bias", True))
+            known.update(intermediate_size=hs * int(raw.get("mlp_ratio", 4)), query_bias=qkv_bias, key_bias=qkv_bias,
+                         value_bias=qkv_bias, use_gated_mlp=bool(raw.get("use_swiglu_ffn", False)), use_rope=False,
+                         layer_norm_eps=float(raw.get("layer_norm_eps", 1e-6)),
+                         num_register_tokens=int(raw.get("num_register_tokens", 4)),
+                         patch_size=int(known.get("patch_size", 16)), image_size=int(known.get("image_size", 224)))
+            known["pos_embed_grid"] = known["image_size"] // known["patch_size"]
         return cls(**known)
 
 
@@ -95,7 +116,16 @@ VIT_L16 = ViTConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=
 VIT_TINY = ViTConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
                      image_size=64)
 
-NAMED_VIT = {"vits16": VIT_S16, "vitb16": VIT_B16, "vitl16": VIT_L16, "tiny": VIT_TINY}
+# DINOv2-with-registers (CBAS's default encoder, "facebook/dinov2-with-registers-base"): ViT-B/14 trained at 518
+DINOV2_REG_B14 = ViTConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                           patch_size=14, image_size=518, layer_norm_eps=1e-6, key_bias=True,
+                           model_type="dinov2_with_registers", use_rope=False, pos_embed_grid=37)
+DINOV2_REG_TINY = ViTConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                            patch_size=14, image_size=70, layer_norm_eps=1e-6, key_bias=True,
+                            model_type="dinov2_with_registers", use_rope=False, pos_embed_grid=5)
+
+NAMED_VIT = {"vits16": VIT_S16, "vitb16": VIT_B16, "vitl16": VIT_L16, "tiny": VIT_TINY,
+             "dinov2regb14": DINOV2_REG_B14, "dinov2regtiny": DINOV2_REG_TINY}
 
 
 @dataclass(frozen=True)

@@ -59,6 +59,9 @@ struct cbas_enc {
     f16 *w16 = nullptr, *w16_lo = nullptr;     // all fp16 weights (hi / lo)
     f16 *wpatch, *wpatch2, *wpatch_lo, *wpatch2_lo;
     float* qkv_bias_all = nullptr;
+    float* prefix_dev = nullptr;        // (1+R, D): cls (+ its position embedding for DINOv2) | registers
+    float* pos_tab = nullptr;           // DINOv2: (Pmax, D) position embedding interpolated to the current grid
+    std::vector<float> pos_host;        // DINOv2: raw (1+G*G, D) table
     // rope tables for the last resolution
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_nh = 0, rope_nw = 0, rope_cap = 0;
@@ -86,14 +89,82 @@ namespace {
 
 int64_t weights_count(const cbas_enc_config& c) {
     const int64_t D = c.hidden_size, F = c.intermediate_size, R = c.num_register_tokens, p = c.patch_size;
-    int64_t n = D + R * D + D * 3 * p * p + D;
-    const int64_t per = 2 * D + (D * D + D) + D * D + (D * D + D) + (D * D + D) + D + 2 * D + (F * D + F) + (D * F + D) + D;
+    const int64_t G = c.pos_embed_grid;
+    int64_t n = D + R * D + (G > 0 ? (1 + G * G) * D : 0) + D * 3 * p * p + D;
+    const int64_t per = 2 * D + (D * D + D) + (D * D + D) + (D * D + D) + (D * D + D) + D + 2 * D + (F * D + F) + (D * F + D) + D;
     n += per * c.num_layers;
     n += 2 * D;
     return n;
 }
 
+// Keys cubic kernel, a = -0.5: the coefficient ATen's ANTIALIASED bicubic uses (UpSampleKernel.cpp aa_filter)
+static inline double cubic_aa(double x) {
+    const double a = -0.5;
+    x = fabs(x);
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0;
+    if (x < 2.0) return (((x - 5.0) * x + 8.0) * x - 4.0) * a;
+    return 0.0;
+}
+
+// (out, in) weights of F.interpolate(mode="bicubic", align_corners=False, antialias=True) along one axis
+static std::vector<float> aa_bicubic_matrix(int in_size, int out_size) {
+    std::vector<float> W((size_t)out_size * in_size, 0.f);
+    const double scale = (double)in_size / out_size;
+    const double support = scale >= 1.0 ? 2.0 * scale : 2.0, invscale = scale >= 1.0 ? 1.0 / scale : 1.0;
+    for (int i = 0; i < out_size; ++i) {
+        const double center = scale * (i + 0.5);
+        int xmin = (int)(center - support + 0.5); if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5); if (xmax > in_size) xmax = in_size;
+        double tot = 0.0;
+        for (int j = xmin; j < xmax; ++j) tot += cubic_aa((j - center + 0.5) * invscale);
+        for (int j = xmin; j < xmax; ++j) W[(size_t)i * in_size + j] = (float)(cubic_aa((j - center + 0.5) * invscale) / tot);
+    }
+    return W;
+}
+
+// DINOv2: position embedding of the patch tokens for an nh x nw grid ([v2] interpolate_pos_encoding :93-145)
+int ensure_pos_embed(cbas_enc* h, int nh, int nw, hipStream_t stream) {
+    if (h->rope_nh == nh && h->rope_nw == nw) return CBAS_OK;
+    const int P = nh * nw, G = h->cfg.pos_embed_grid, D = h->D;
+    if (P > h->rope_cap) return cbas_fail(CBAS_EINVAL, "frame has %d patches, workspace holds %d", P, h->rope_cap);
+    const float* src = h->pos_host.data() + D;               // skip the cls position
+    std::vector<float> out((size_t)P * D);
+    if (nh == G && nw == G) {
+        memcpy(out.data(), src, out.size() * 4);
+    } else {
+        const std::vector<float> Wh = aa_bicubic_matrix(G, nh), Ww = aa_bicubic_matrix(G, nw);
+        std::vector<float> tmp((size_t)G * nw * D, 0.f);     // width pass, then height pass (separable)
+        for (int i = 0; i < G; ++i)
+            for (int x = 0; x < nw; ++x) {
+                float* t = &tmp[((size_t)i * nw + x) * D];
+                for (int j = 0; j < G; ++j) {
+                    const float w = Ww[(size_t)x * G + j];
+                    if (w == 0.f) continue;
+                    const float* sp = src + ((size_t)i * G + j) * D;
+                    for (int d = 0; d < D; ++d) t[d] += w * sp[d];
+                }
+            }
+        std::fill(out.begin(), out.end(), 0.f);
+        for (int y = 0; y < nh; ++y)
+            for (int i = 0; i < G; ++i) {
+                const float w = Wh[(size_t)y * G + i];
+                if (w == 0.f) continue;
+                for (int x = 0; x < nw; ++x) {
+                    float* o = &out[((size_t)y * nw + x) * D];
+                    const float* t = &tmp[((size_t)i * nw + x) * D];
+                    for (int d = 0; d < D; ++d) o[d] += w * t[d];
+                }
+            }
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(h->pos_tab, out.data(), out.size() * 4, hipMemcpyHostToDevice));
+    h->rope_nh = nh;
+    h->rope_nw = nw;
+    return CBAS_OK;
+}
+
 int ensure_rope(cbas_enc* h, int nh, int nw, hipStream_t stream) {
+    if (!h->cfg.use_rope) return ensure_pos_embed(h, nh, nw, stream);
     if (h->rope_nh == nh && h->rope_nw == nw) return CBAS_OK;
     const int P = nh * nw;
     if (P > h->rope_cap) return cbas_fail(CBAS_EINVAL, "frame has %d patches, workspace holds %d", P, h->rope_cap);
@@ -127,8 +198,9 @@ int ensure_rope(cbas_enc* h, int nh, int nw, hipStream_t stream) {
 int check_frame(cbas_enc* h, int n, int height, int width) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
     if (n <= 0 || n > h->cfg.max_batch) return cbas_fail(CBAS_EINVAL, "n=%d outside (0, max_batch=%d]", n, h->cfg.max_batch);
-    if (height < 16 || width < 16) return cbas_fail(CBAS_EINVAL, "frame %dx%d smaller than one patch", height, width);
-    const int64_t P = (int64_t)(height / 16) * (width / 16);
+    const int ps = h->cfg.patch_size;
+    if (height < ps || width < ps) return cbas_fail(CBAS_EINVAL, "frame %dx%d smaller than one patch", height, width);
+    const int64_t P = (int64_t)(height / ps) * (width / ps);
     if ((int64_t)n * (P + h->NP) > h->rows_cap || (int64_t)n * P > h->prow_cap)
         return cbas_fail(CBAS_EINVAL, "%d frames of %dx%d exceed the workspace (max_batch=%d, %dx%d)", n, height,
                          width, h->cfg.max_batch, h->cfg.max_height, h->cfg.max_width);
@@ -156,7 +228,8 @@ struct ProfScope {
 // Everything after ingest: patch GEMM, L transformer blocks, final CLS norm.
 int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_scale, float* cls_f32,
                f16* cls_f16, hipStream_t st, int stop_layer, int stop_stage) {
-    const int nh = height / 16, nw = width / 16, P = nh * nw, T = P + h->NP;
+    const int ps = h->cfg.patch_size;
+    const int nh = height / ps, nw = width / ps, P = nh * nw, T = P + h->NP;
     const int D = h->D, F = h->F;
     const int M = n * T, M_pad = (int)round_up(M, 128);
     h->last_rows = M;
@@ -170,6 +243,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     g.M = n * P; g.M_pad = (int)round_up(n * P, 128); g.N = D; g.K = patch_k;
     g.bias = h->patch_b; g.out_f32 = h->x; g.ldo = D;
     g.patches_per_frame = P; g.tokens_per_frame = T; g.n_prefix = h->NP; g.in_scale = in_scale;
+    g.pos = h->cfg.use_rope ? nullptr : h->pos_tab;
     { PROF(CBAS_PROF_PATCH, 2.0 * g.M * g.N * g.K); LAUNCH_TRY(launch_gemm(EPI_PATCH, g, st)); }
     if (stop_layer == 0 && stop_stage == 0) return CBAS_OK;
 
@@ -182,7 +256,8 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
         GemmParams q{};
         q.A = h->h16; q.W = w.wqkv; q.W_lo = h->cfg.precision ? w.wqkv_lo : nullptr;
         q.M = M; q.M_pad = M_pad; q.N = 3 * D; q.K = D; q.bias = w.qkv_b; q.out_f16 = h->qkv16; q.ldo = 3 * D;
-        q.tokens_per_frame = T; q.n_prefix = h->NP; q.rope_cos = h->rope_cos; q.rope_sin = h->rope_sin; q.D = D;
+        q.tokens_per_frame = T; q.n_prefix = h->NP; q.D = D;
+        q.rope_cos = h->cfg.use_rope ? h->rope_cos : nullptr; q.rope_sin = h->cfg.use_rope ? h->rope_sin : nullptr;
         { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
         if (stop(2)) return CBAS_OK;
 
@@ -219,9 +294,10 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
 int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
                    int64_t row_stride, int64_t pixel_stride, float* cls_f32, f16* cls_f16, hipStream_t st,
                    int stop_layer, int stop_stage) {
-    const int T = (height / 16) * (width / 16) + h->NP;
+    const int ps = h->cfg.patch_size;
+    const int T = (height / ps) * (width / ps) + h->NP;
     LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
-                                h->x, h->prefix, h->NP, h->D, T, st));
+                                h->x, h->prefix, h->NP, h->D, T, ps, st));
     return run_blocks(h, n, height, width, 256, 1.0f / 255.0f, cls_f32, cls_f16, st, stop_layer, stop_stage);
 }
 
@@ -246,7 +322,7 @@ int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int wi
     // Two half-batches on two internal streams: one half's kernel tails, LayerNorm, attention and
     // epilogues overlap the other half's GEMM main loops.  Results are bit-identical to the
     // single-lane order (rows are independent).
-    rc = ensure_rope(h, height / 16, width / 16, st);
+    rc = ensure_rope(h, height / h->cfg.patch_size, width / h->cfg.patch_size, st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_fork, st));
     const int n0 = (n + 1) / 2;
@@ -297,7 +373,7 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
         void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16};
         for (void* b : b1) if (b) (void)hipFree(b);
     }
-    void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->rope_cos, h->rope_sin,
+    void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->rope_cos, h->rope_sin, h->prefix_dev, h->pos_tab,
                     h->A_patch, h->h16, h->qkv16, h->u16, h->x};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -317,8 +393,10 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     if (c.intermediate_size <= 0 || c.intermediate_size % 128)
         return cbas_fail(CBAS_EINVAL, "intermediate_size=%d must be a multiple of 128", c.intermediate_size);
     if (c.hidden_size > 1024) return cbas_fail(CBAS_EINVAL, "hidden_size > 1024 not supported");
-    if (c.patch_size != 16) return cbas_fail(CBAS_EINVAL, "patch_size must be 16");
-    if (c.num_layers <= 0 || c.num_register_tokens < 0 || c.max_batch <= 0 || c.max_height < 16 || c.max_width < 16)
+    if (c.patch_size != 16 && c.patch_size != 14) return cbas_fail(CBAS_EINVAL, "patch_size must be 14 or 16");
+    if ((c.use_rope != 0) == (c.pos_embed_grid > 0))
+        return cbas_fail(CBAS_EINVAL, "exactly one of use_rope / pos_embed_grid must be set");
+    if (c.num_layers <= 0 || c.num_register_tokens < 0 || c.max_batch <= 0 || c.max_height < c.patch_size || c.max_width < c.patch_size)
         return cbas_fail(CBAS_EINVAL, "bad layer/register/batch/frame-size field");
     if (n_weights != weights_count(c))
         return cbas_fail(CBAS_EINVAL, "weights blob has %lld floats, config needs %lld", (long long)n_weights,
@@ -360,13 +438,26 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     f16* wl = h->w16_lo;
     auto lo = [&](f16* hi_ptr) -> f16* { return wl ? wl + (hi_ptr - h->w16) : nullptr; };
 
-    h->prefix = p; p += (1 + h->R) * D;                 // cls_token | register_tokens: rows of the prefix
-    const float* patch_w = p; p += D * 768;
+    // prefix rows of every frame: cls_token (+ its position embedding, DINOv2 [v2]:158-161) | register_tokens
+    {
+        const int64_t G = c.pos_embed_grid;
+        std::vector<float> pre(weights_host, weights_host + (1 + h->R) * D);
+        if (G > 0) {
+            const float* pos = weights_host + (1 + h->R) * D;
+            h->pos_host.assign(pos, pos + (1 + G * G) * D);
+            for (int64_t d = 0; d < D; ++d) pre[d] += pos[d];
+        }
+        CREATE_TRY(hipMalloc(&h->prefix_dev, pre.size() * sizeof(float)));
+        CREATE_TRY(hipMemcpy(h->prefix_dev, pre.data(), pre.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->prefix = h->prefix_dev;
+        p += (1 + h->R) * D + (G > 0 ? (1 + G * G) * D : 0);
+    }
+    const float* patch_w = p; p += D * 3 * c.patch_size * c.patch_size;
     h->patch_b = p; p += D;
     h->wpatch = w; w += D * 256;
     h->wpatch2 = w; w += D * 512;
     h->wpatch_lo = lo(h->wpatch); h->wpatch2_lo = lo(h->wpatch2);
-    int rc = launch_pack_patch_weight(patch_w, h->wpatch, h->wpatch_lo, h->wpatch2, h->wpatch2_lo, (int)D, st);
+    int rc = launch_pack_patch_weight(patch_w, h->wpatch, h->wpatch_lo, h->wpatch2, h->wpatch2_lo, (int)D, c.patch_size, st);
 
     h->layers.resize(h->L);
     for (int l = 0; l < h->L && !rc; ++l) {
@@ -377,6 +468,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         const float* qw = p; p += D * D;
         const float* qb = p; p += D;
         const float* kw = p; p += D * D;
+        const float* kb = p; p += D;
         const float* vw = p; p += D * D;
         const float* vb = p; p += D;
         const float* ow = p; p += D * D;
@@ -401,6 +493,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         rc |= launch_convert_f16(uw, lw.wup, lw.wup_lo, F * D, st);
         rc |= launch_convert_f16(dw, lw.wdown, lw.wdown_lo, D * F, st);
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b, qb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CREATE_TRY(hipMemcpyAsync(lw.qkv_b + D, kb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b + 2 * D, vb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     h->norm_w = p; p += D;
@@ -413,13 +506,14 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     }
 
     // workspaces
-    const int64_t Pmax = (int64_t)(c.max_height / 16) * (c.max_width / 16);
+    const int64_t Pmax = (int64_t)(c.max_height / c.patch_size) * (c.max_width / c.patch_size);
     const int64_t Tmax = Pmax + h->NP;
     h->rows_cap = round_up((int64_t)c.max_batch * Tmax, 128);
     h->prow_cap = round_up((int64_t)c.max_batch * Pmax, 128);
     h->rope_cap = (int)Pmax;
     CREATE_TRY(hipMalloc(&h->rope_cos, Pmax * 64 * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->rope_sin, Pmax * 64 * sizeof(float)));
+    if (c.pos_embed_grid > 0) CREATE_TRY(hipMalloc(&h->pos_tab, Pmax * D * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->A_patch, h->prow_cap * 512 * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->x, h->rows_cap * D * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->h16, h->rows_cap * D * sizeof(f16)));
@@ -494,8 +588,9 @@ extern "C" int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int 
     if (!x_dev) return cbas_fail(CBAS_EINVAL, "x_dev is NULL");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    const int T = (height / 16) * (width / 16) + h->NP;
-    LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, st));
+    const int ps = h->cfg.patch_size;
+    const int T = (height / ps) * (width / ps) + h->NP;
+    LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, ps, st));
     return run_blocks(h, n, height, width, 512, 1.0f, cls_f32_dev, (f16*)cls_f16_dev, st, -1, -1);
 }
 

@@ -18,13 +18,15 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
         for (int j = 0; j < 4; ++j) {
             const int n = ncol + j * 16;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-            const f32x4 v = acc[j] * p.in_scale + bv;
+            f32x4 v = acc[j] * p.in_scale + bv;
+            if (p.pos)    // DINOv2: learned position embedding of patch (m - b*P), [v2]:161
+                v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)(m - b * p.patches_per_frame) * p.N + n);
             *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)orow * p.ldo + n) = v;
         }
     } else if (EPI == EPI_QKV) {
         const int sec = head_col0 / p.D;               // 0 q, 1 k, 2 v: uniform over the 64-column group
         const int t = m % p.tokens_per_frame;
-        const bool rope = (sec < 2) && (t >= p.n_prefix);
+        const bool rope = p.rope_cos && (sec < 2) && (t >= p.n_prefix);
         f32x4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + ncol + j * 16);
@@ -145,7 +147,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 if (EPI == EPI_QKV) {
                     const int m = row_base + i * 16 + li;
                     const int t = m % p.tokens_per_frame;
-                    if (sec < 2 && t >= p.n_prefix) {
+                    if (p.rope_cos && sec < 2 && t >= p.n_prefix) {
                         // the table is angles.tile(2) ([tf]:190): columns d and d+32 hold the same value,
                         // so two loads per table serve all four 16-column groups
                         const size_t ro = (size_t)(t - p.n_prefix) * 64 + g * 4;

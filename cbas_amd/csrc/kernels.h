@@ -40,8 +40,9 @@ struct GemmParams {
     int tokens_per_frame;    // T
     int n_prefix;            // 1 + R
     float in_scale;          // 1/255 for uint8 input, 1 for float input
+    const float* pos;        // [P][N] additive position embedding for the frame's patch grid, or nullptr (DINOv3)
     // EPI_QKV
-    const float* rope_cos;   // [P][64]
+    const float* rope_cos;   // [P][64], or nullptr: no RoPE (DINOv2)
     const float* rope_sin;   // [P][64]
     int D;                   // hidden size (q | k | v sections of width D)
 };
@@ -56,10 +57,10 @@ int launch_gemm_ring(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_
 // also writes the CLS/register prefix rows of the residual stream x.
 int launch_im2col_u8(const uint8_t* frames, int n, int height, int width, int64_t frame_stride,
                      int64_t row_stride, int64_t pixel_stride, f16* A, float* x, const float* prefix_tokens,
-                     int n_prefix, int D, int T, hipStream_t stream);
+                     int n_prefix, int D, int T, int ps, hipStream_t stream);
 // float32 (n,H,W) in [0,1] -> A[n*P][512] fp16 as hi|lo halves along K (x = hi + lo to ~2^-22)
 int launch_im2col_f32(const float* frames, int n, int height, int width, f16* A, float* x,
-                      const float* prefix_tokens, int n_prefix, int D, int T, hipStream_t stream);
+                      const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream);
 
 // LayerNorm over the last dim (fp32 in, fp16 out), rows = M
 int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, f16* out, int M, int D,
@@ -75,7 +76,7 @@ int launch_attention(const f16* qkv, f16* out, int n, int T, int D, int n_heads,
 int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t stream);
 // patch weight (D,3,16,16) fp32 -> sum over the 3 identical input channels -> (D,256) fp16 hi (+lo),
 // and the same duplicated along K as (D,512) for the float-input path
-int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, hipStream_t stream);
+int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, int ps, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // classifier head (all fp32)

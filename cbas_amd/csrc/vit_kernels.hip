@@ -14,24 +14,27 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // ingest
 // ---------------------------------------------------------------------------------------------
-// One thread = one 16-pixel patch row.  A[m][i*16 + j], m = b*P + py*nw + px.
+// One thread = one patch row of `ps` pixels (ps = 16 for DINOv3, 14 for DINOv2).  A[m][i*16 + j],
+// m = b*P + py*nw + px; the K layout always has 16x16 slots per patch: slots with i >= ps or j >= ps
+// stay zero (rows i >= ps are never written; the buffer is zeroed at allocation) and the packed
+// patch weights are zero there too.
 __global__ void im2col_u8_kernel(const uint8_t* __restrict__ frames, int n, int height, int width,
                                  int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
-                                 f16* __restrict__ A, int nh, int nw) {
+                                 f16* __restrict__ A, int nh, int nw, int ps) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)n * nh * 16 * nw;
+    const int64_t total = (int64_t)n * nh * ps * nw;
     if (gid >= total) return;
     const int px = gid % nw;
     const int64_t t1 = gid / nw;
-    const int y = t1 % (nh * 16);
-    const int b = t1 / (nh * 16);
-    const int py = y >> 4, i = y & 15;
-    const uint8_t* src = frames + b * frame_stride + (int64_t)y * row_stride + (int64_t)px * 16 * pixel_stride;
+    const int y = t1 % (nh * ps);
+    const int b = t1 / (nh * ps);
+    const int py = y / ps, i = y - py * ps;
+    const uint8_t* src = frames + b * frame_stride + (int64_t)y * row_stride + (int64_t)px * ps * pixel_stride;
     f16x8 lo, hi;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lo[j] = (f16)(float)src[j * pixel_stride];
-        hi[j] = (f16)(float)src[(j + 8) * pixel_stride];
+        lo[j] = (f16)(float)src[j * pixel_stride];                       // ps >= 14 > 8
+        hi[j] = (j + 8 < ps) ? (f16)(float)src[(j + 8) * pixel_stride] : (f16)0.f;
     }
     f16* dst = A + ((int64_t)b * nh * nw + (int64_t)py * nw + px) * 256 + i * 16;
     *reinterpret_cast<f16x8*>(dst) = lo;
@@ -40,23 +43,23 @@ __global__ void im2col_u8_kernel(const uint8_t* __restrict__ frames, int n, int 
 
 // float input: K = 512, columns [0,256) hold fp16(x), [256,512) hold fp16(x - fp16(x)).
 __global__ void im2col_f32_kernel(const float* __restrict__ frames, int n, int height, int width,
-                                  f16* __restrict__ A, int nh, int nw) {
+                                  f16* __restrict__ A, int nh, int nw, int ps) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)n * nh * 16 * nw;
+    const int64_t total = (int64_t)n * nh * ps * nw;
     if (gid >= total) return;
     const int px = gid % nw;
     const int64_t t1 = gid / nw;
-    const int y = t1 % (nh * 16);
-    const int b = t1 / (nh * 16);
-    const int py = y >> 4, i = y & 15;
-    const float* src = frames + ((int64_t)b * height + y) * width + px * 16;
+    const int y = t1 % (nh * ps);
+    const int b = t1 / (nh * ps);
+    const int py = y / ps, i = y - py * ps;
+    const float* src = frames + ((int64_t)b * height + y) * width + px * ps;
     f16* dst = A + ((int64_t)b * nh * nw + (int64_t)py * nw + px) * 512 + i * 16;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         f16x8 h, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = src[half * 8 + j];
+            const float v = (half * 8 + j < ps) ? src[half * 8 + j] : 0.f;
             const f16 hv = (f16)v;
             h[j] = hv;
             l[j] = (f16)(v - (float)hv);
@@ -454,20 +457,24 @@ __global__ void convert_f16_kernel(const float* __restrict__ src, f16* __restric
     if (lo) lo[i] = (f16)(v - (float)h);
 }
 
-// hi/lo: (D,256); hi2/lo2: (D,512) = [W' | W'] for the float-input path (fp16(x) | residual share W')
+// w: (D,3,ps,ps).  hi/lo: (D,256) with the 16x16 slot layout (zero where i >= ps or j >= ps);
+// hi2/lo2: (D,512) = [W' | W'] for the float-input path (fp16(x) | residual share W')
 __global__ void pack_patch_weight_kernel(const float* __restrict__ w, f16* __restrict__ hi, f16* __restrict__ lo,
-                                         f16* __restrict__ hi2, f16* __restrict__ lo2, int D) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over D*256
-    if (i >= D * 256) return;
-    const int d = i >> 8, k = i & 255;
-    const float* base = w + (size_t)d * 768 + k;
-    const float v = (base[0] + base[256]) + base[512];       // sum over the 3 identical input channels
+                                         f16* __restrict__ hi2, f16* __restrict__ lo2, int D, int ps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over D*256
+    if (idx >= D * 256) return;
+    const int d = idx >> 8, k = idx & 255, i = k >> 4, j = k & 15;
+    float v = 0.f;
+    if (i < ps && j < ps) {
+        const float* base = w + (size_t)d * 3 * ps * ps + i * ps + j;
+        v = (base[0] + base[ps * ps]) + base[2 * ps * ps];     // sum over the 3 identical input channels
+    }
     const f16 h = (f16)v;
     const f16 l = (f16)(v - (float)h);
-    hi[i] = h;
+    hi[idx] = h;
     hi2[d * 512 + k] = h;
     hi2[d * 512 + 256 + k] = h;
-    if (lo) { lo[i] = l; lo2[d * 512 + k] = l; lo2[d * 512 + 256 + k] = l; }
+    if (lo) { lo[idx] = l; lo2[d * 512 + k] = l; lo2[d * 512 + 256 + k] = l; }
 }
 
 }  // namespace
@@ -476,11 +483,11 @@ __global__ void pack_patch_weight_kernel(const float* __restrict__ w, f16* __res
 
 int launch_im2col_u8(const uint8_t* frames, int n, int height, int width, int64_t frame_stride,
                      int64_t row_stride, int64_t pixel_stride, f16* A, float* x, const float* prefix_tokens,
-                     int n_prefix, int D, int T, hipStream_t stream) {
-    const int nh = height / 16, nw = width / 16;
-    const int64_t total = (int64_t)n * nh * 16 * nw;
+                     int n_prefix, int D, int T, int ps, hipStream_t stream) {
+    const int nh = height / ps, nw = width / ps;
+    const int64_t total = (int64_t)n * nh * ps * nw;
     hipLaunchKernelGGL(im2col_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
-                       height, width, frame_stride, row_stride, pixel_stride, A, nh, nw);
+                       height, width, frame_stride, row_stride, pixel_stride, A, nh, nw, ps);
     const int64_t tp = (int64_t)n * n_prefix * (D / 4);
     hipLaunchKernelGGL(write_prefix_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens,
                        n, n_prefix, D, T);
@@ -488,11 +495,11 @@ int launch_im2col_u8(const uint8_t* frames, int n, int height, int width, int64_
 }
 
 int launch_im2col_f32(const float* frames, int n, int height, int width, f16* A, float* x,
-                      const float* prefix_tokens, int n_prefix, int D, int T, hipStream_t stream) {
-    const int nh = height / 16, nw = width / 16;
-    const int64_t total = (int64_t)n * nh * 16 * nw;
+                      const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream) {
+    const int nh = height / ps, nw = width / ps;
+    const int64_t total = (int64_t)n * nh * ps * nw;
     hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
-                       height, width, A, nh, nw);
+                       height, width, A, nh, nw, ps);
     const int64_t tp = (int64_t)n * n_prefix * (D / 4);
     hipLaunchKernelGGL(write_prefix_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens,
                        n, n_prefix, D, T);
@@ -544,7 +551,7 @@ int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_
     return CHECK_LAUNCH();
 }
 
-int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_patch_weight_kernel, dim3((D * 256 + 255) / 256), dim3(256), 0, stream, w, hi, lo, hi2, lo2, D);
+int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, int ps, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_patch_weight_kernel, dim3((D * 256 + 255) / 256), dim3(256), 0, stream, w, hi, lo, hi2, lo2, D, ps);
     return CHECK_LAUNCH();
 }

@@ -24,13 +24,19 @@ from .weights import load_encoder_checkpoint
 
 def pack_encoder_weights(cfg: ViTConfig, w: Dict[str, np.ndarray]) -> np.ndarray:
     """Flatten an HF state dict into the blob order documented in include/cbas_mi355x.h."""
+    from .weights import canonical_encoder_weights
+    w = dict(canonical_encoder_weights(cfg, w))    # DINOv2-with-registers keys -> the DINOv3 names used below
     D = cfg.hidden_size
-    parts = [w["embeddings.cls_token"].reshape(-1), w["embeddings.register_tokens"].reshape(-1),
-             w["embeddings.patch_embeddings.weight"].reshape(-1), w["embeddings.patch_embeddings.bias"].reshape(-1)]
+    parts = [w["embeddings.cls_token"].reshape(-1), w["embeddings.register_tokens"].reshape(-1)]
+    if cfg.pos_embed_grid > 0:
+        parts.append(w["embeddings.position_embeddings"].reshape(-1))
+    parts += [w["embeddings.patch_embeddings.weight"].reshape(-1), w["embeddings.patch_embeddings.bias"].reshape(-1)]
+    zero_kb = np.zeros(D, np.float32)
     for i in range(cfg.num_hidden_layers):
         p = f"model.layer.{i}."
+        w.setdefault(p + "attention.k_proj.bias", zero_kb)       # DINOv3 has no key bias ([tf] key_bias=False)
         for k in ("norm1.weight", "norm1.bias", "attention.q_proj.weight", "attention.q_proj.bias",
-                  "attention.k_proj.weight", "attention.v_proj.weight", "attention.v_proj.bias",
+                  "attention.k_proj.weight", "attention.k_proj.bias", "attention.v_proj.weight", "attention.v_proj.bias",
                   "attention.o_proj.weight", "attention.o_proj.bias", "layer_scale1.lambda1",
                   "norm2.weight", "norm2.bias", "mlp.up_proj.weight", "mlp.up_proj.bias",
                   "mlp.down_proj.weight", "mlp.down_proj.bias", "layer_scale2.lambda1"):
@@ -77,7 +83,7 @@ class DinoEncoder:
         self._cfg_c = _lib.EncConfig(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers,
                                      cfg.num_attention_heads, cfg.num_register_tokens, cfg.patch_size,
                                      cfg.layer_norm_eps, cfg.rope_theta, self.max_batch, self.max_frame[0],
-                                     self.max_frame[1], int(precision))
+                                     self.max_frame[1], int(precision), int(cfg.use_rope), int(cfg.pos_embed_grid))
         blob = pack_encoder_weights(cfg, weights)
         need = self._lib.cbas_enc_weights_count(C.byref(self._cfg_c))
         if need != blob.shape[0]:

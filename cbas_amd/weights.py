@@ -64,7 +64,60 @@ def synth_uniform(seed: int, name: str, shape: Tuple[int, ...], lo: float, hi: f
 # Encoder
 # ----------------------------------------------------------------------------------------------
 
+def _dinov2_param_shapes(cfg: ViTConfig) -> Dict[str, Tuple[int, ...]]:
+    """HF ``Dinov2WithRegistersModel`` state-dict keys (modeling_dinov2_with_registers.py:75-92, 203-320, 362-381, 455-470)."""
+    D, F, R, p, C, G = (cfg.hidden_size, cfg.intermediate_size, cfg.num_register_tokens, cfg.patch_size,
+                        cfg.num_channels, cfg.pos_embed_grid)
+    s: Dict[str, Tuple[int, ...]] = {
+        "embeddings.cls_token": (1, 1, D),
+        "embeddings.mask_token": (1, D),
+        "embeddings.register_tokens": (1, R, D),
+        "embeddings.position_embeddings": (1, 1 + G * G, D),
+        "embeddings.patch_embeddings.projection.weight": (D, C, p, p),
+        "embeddings.patch_embeddings.projection.bias": (D,),
+        "layernorm.weight": (D,),
+        "layernorm.bias": (D,),
+    }
+    for i in range(cfg.num_hidden_layers):
+        pre = f"encoder.layer.{i}."
+        for nm, shp in (("norm1.weight", (D,)), ("norm1.bias", (D,)),
+                        ("attention.attention.query.weight", (D, D)), ("attention.attention.query.bias", (D,)),
+                        ("attention.attention.key.weight", (D, D)), ("attention.attention.key.bias", (D,)),
+                        ("attention.attention.value.weight", (D, D)), ("attention.attention.value.bias", (D,)),
+                        ("attention.output.dense.weight", (D, D)), ("attention.output.dense.bias", (D,)),
+                        ("layer_scale1.lambda1", (D,)), ("norm2.weight", (D,)), ("norm2.bias", (D,)),
+                        ("mlp.fc1.weight", (F, D)), ("mlp.fc1.bias", (F,)), ("mlp.fc2.weight", (D, F)),
+                        ("mlp.fc2.bias", (D,)), ("layer_scale2.lambda1", (D,))):
+            s[pre + nm] = shp
+    return s
+
+
+_V2_TO_CANON = (("embeddings.patch_embeddings.projection.", "embeddings.patch_embeddings."),
+                ("encoder.layer.", "model.layer."), ("attention.attention.query.", "attention.q_proj."),
+                ("attention.attention.key.", "attention.k_proj."), ("attention.attention.value.", "attention.v_proj."),
+                ("attention.output.dense.", "attention.o_proj."), ("mlp.fc1.", "mlp.up_proj."),
+                ("mlp.fc2.", "mlp.down_proj."), ("layernorm.", "norm."))
+
+
+def canonical_encoder_weights(cfg: ViTConfig, w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Rename a DINOv2-with-registers state dict to the DINOv3 key names the packer and the oracle use
+    (same tensors, same shapes); a DINOv3 state dict is returned unchanged."""
+    if cfg.model_type != "dinov2_with_registers":
+        return w
+    out = {}
+    for k, v in w.items():
+        for a, b in _V2_TO_CANON:
+            if k.startswith(a):
+                k = b + k[len(a):]
+            elif a in k and not a.startswith("embeddings") and not a.startswith("encoder") and not a.startswith("layernorm"):
+                k = k.replace(a, b)
+        out[k] = v
+    return out
+
+
 def encoder_param_shapes(cfg: ViTConfig) -> Dict[str, Tuple[int, ...]]:
+    if cfg.model_type == "dinov2_with_registers":
+        return _dinov2_param_shapes(cfg)
     D, F, R, p, C = cfg.hidden_size, cfg.intermediate_size, cfg.num_register_tokens, cfg.patch_size, cfg.num_channels
     s: Dict[str, Tuple[int, ...]] = {
         "embeddings.cls_token": (1, 1, D),
@@ -107,6 +160,8 @@ def synth_encoder_weights(cfg: ViTConfig, seed: int = 1234) -> Dict[str, np.ndar
             w = np.zeros(shape, np.float32)
         elif "cls_token" in name or "register_tokens" in name:
             w = synth_normal(seed, name, shape, 0.5)
+        elif "position_embeddings" in name:
+            w = synth_normal(seed, name, shape, 0.3)
         elif "lambda1" in name:
             w = synth_uniform(seed, name, shape, 0.2, 1.0)
         elif "norm" in name and leaf == "weight":
@@ -115,9 +170,9 @@ def synth_encoder_weights(cfg: ViTConfig, seed: int = 1234) -> Dict[str, np.ndar
             w = synth_uniform(seed, name, shape, -0.2, 0.2)
         elif leaf == "bias":
             w = synth_uniform(seed, name, shape, -0.1, 0.1)
-        elif "q_proj" in name or "k_proj" in name:
+        elif "q_proj" in name or "k_proj" in name or ".query." in name or ".key." in name:
             w = synth_normal(seed, name, shape, 0.05)
-        elif "patch_embeddings.weight" in name:
+        elif "patch_embeddings.weight" in name or "projection.weight" in name:
             w = synth_normal(seed, name, shape, 0.03)
         else:
             w = synth_normal(seed, name, shape, 0.02)

@@ -49,7 +49,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   1
+#define CBAS_ABI_VERSION   2
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -63,7 +63,7 @@ typedef struct cbas_enc_config {
     int32_t num_layers;           /* L                                         */
     int32_t num_heads;            /* D / 64 (head_dim must be 64)              */
     int32_t num_register_tokens;  /* R (4 for the released checkpoints)        */
-    int32_t patch_size;           /* 16                                        */
+    int32_t patch_size;           /* 16 (DINOv3) or 14 (DINOv2)                */
     float   layer_norm_eps;       /* 1e-5                                      */
     float   rope_theta;           /* 100                                       */
     int32_t max_batch;            /* frames per encoder pass (workspace size)  */
@@ -71,11 +71,15 @@ typedef struct cbas_enc_config {
     int32_t max_width;
     int32_t precision;            /* 0: fp16 operands, fp32 accumulate/residual (default)
                                      1: fp16 hi+lo split weights (2 MFMA/k-step) */
+    int32_t use_rope;             /* 1: DINOv3 (RoPE on patch rows, no additive position embedding)     */
+    int32_t pos_embed_grid;       /* G > 0: DINOv2-with-registers, learned (1+G*G, D) position embedding,
+                                     bicubic-antialias interpolated to each frame's patch grid; else 0 */
 } cbas_enc_config;
 
 /* Number of float32 elements cbas_enc_create expects in `weights`, in this order:
- *   cls_token[D], register_tokens[R*D], patch_weight[D*3*16*16], patch_bias[D],
- *   then per layer: norm1.w[D] norm1.b[D] q.w[D*D] q.b[D] k.w[D*D] v.w[D*D] v.b[D] o.w[D*D] o.b[D]
+ *   cls_token[D], register_tokens[R*D], position_embeddings[(1+G*G)*D] (only when pos_embed_grid = G > 0),
+ *   patch_weight[D*3*p*p], patch_bias[D],
+ *   then per layer: norm1.w[D] norm1.b[D] q.w[D*D] q.b[D] k.w[D*D] k.b[D] (zeros for DINOv3) v.w[D*D] v.b[D] o.w[D*D] o.b[D]
  *                   ls1[D] norm2.w[D] norm2.b[D] up.w[F*D] up.b[F] down.w[D*F] down.b[D] ls2[D],
  *   then norm.w[D] norm.b[D].
  * Linear weights are (out_features, in_features) row-major, exactly the HF state_dict tensors. */

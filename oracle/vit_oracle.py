@@ -125,12 +125,13 @@ def attention(x: np.ndarray, w: Dict[str, np.ndarray], pre: str, n_heads: int, c
     q = q.reshape(B, T, n_heads, hd).transpose(0, 2, 1, 3)
     k = k.reshape(B, T, n_heads, hd).transpose(0, 2, 1, 3)
     v = v.reshape(B, T, n_heads, hd).transpose(0, 2, 1, 3)
-    n_prefix = T - cos.shape[0]
-    qp, kp = q[:, :, n_prefix:], k[:, :, n_prefix:]
-    qp = qp * cos + _rotate_half(qp) * sin
-    kp = kp * cos + _rotate_half(kp) * sin
-    q = np.concatenate([q[:, :, :n_prefix], qp], axis=2).astype(F32)
-    k = np.concatenate([k[:, :, :n_prefix], kp], axis=2).astype(F32)
+    if cos is not None:                      # DINOv3 only; DINOv2-with-registers has no RoPE
+        n_prefix = T - cos.shape[0]
+        qp, kp = q[:, :, n_prefix:], k[:, :, n_prefix:]
+        qp = qp * cos + _rotate_half(qp) * sin
+        kp = kp * cos + _rotate_half(kp) * sin
+        q = np.concatenate([q[:, :, :n_prefix], qp], axis=2).astype(F32)
+        k = np.concatenate([k[:, :, :n_prefix], kp], axis=2).astype(F32)
     s = (q @ k.transpose(0, 1, 3, 2)) * F32(hd ** -0.5)
     s = s - s.max(axis=-1, keepdims=True)
     p = np.exp(s, dtype=F32)

@@ -348,7 +348,56 @@ def g_encode_file(out):
         print("encode_file", d.shape, ticks)
 
 
-ALL = {"tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
+def hf_dinov2(cfg: C.ViTConfig, weights):
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    hcfg = Dinov2WithRegistersConfig(
+        hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, mlp_ratio=cfg.intermediate_size // cfg.hidden_size,
+        image_size=cfg.image_size, patch_size=cfg.patch_size, num_register_tokens=cfg.num_register_tokens,
+        layer_norm_eps=cfg.layer_norm_eps, qkv_bias=True)
+    hcfg._attn_implementation = "eager"
+    m = Dinov2WithRegistersModel(hcfg).eval()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.items()}, strict=True)
+    return m
+
+
+def g_dinov2(out):
+    """CBAS's default encoder family (facebook/dinov2-with-registers-base, backend/cbas.py:1030-1033):
+    HF Dinov2WithRegistersModel with synthetic weights.  Tiny config at the native grid (70x70, no
+    interpolation), down-sampled (56x56: 5x5 -> 4x4) and up-sampled (84x84: 5x5 -> 6x6) position
+    embeddings; ViT-B/14 at 224 (37x37 -> 16x16) and at CBAS's 256x256 (-> 18x18, 4 px dropped),
+    the latter through the reference's own DinoEncoder wrapper."""
+    cfg = C.DINOV2_REG_TINY
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    m = hf_dinov2(cfg, w)
+    res = {}
+    for hw in (70, 56, 84):
+        frames = synth.cage_frames(20 + hw, 3, hw, hw)
+        g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()
+        o = m(g.unsqueeze(1).repeat(1, 3, 1, 1), output_hidden_states=True)
+        res[f"emb_{hw}"] = o.hidden_states[0].numpy()
+        res[f"last_{hw}"] = o.last_hidden_state.numpy()
+        res[f"sha_{hw}"] = sha(frames)
+    np.savez_compressed(os.path.join(out, "dinov2reg_tiny.npz"), **res)
+    cfg = C.DINOV2_REG_B14
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    m = hf_dinov2(cfg, w)
+    frames = synth.cage_frames(31, 4, 224, 224)
+    g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()
+    cls224 = torch.cat([m(g[i:i + 2].unsqueeze(1).repeat(1, 3, 1, 1)).last_hidden_state[:, 0] for i in (0, 2)]).numpy()
+    cbas, _ = import_reference()
+    frames256 = synth.cage_frames(32, 2, 256, 256)
+    g = torch.from_numpy(frames256[:, :, :, 1] / 255.0).float()
+    with tempfile.TemporaryDirectory() as td:
+        m.save_pretrained(td)
+        enc = cbas.DinoEncoder(td, device="cpu")                     # reference wrapper, AutoModel -> Dinov2WithRegistersModel
+        cls256 = enc(g.unsqueeze(1)).squeeze(1).numpy()
+    np.savez_compressed(os.path.join(out, "dinov2reg_b14.npz"), cls224=cls224, sha224=sha(frames), cls256=cls256,
+                        sha256=sha(frames256))
+    print("dinov2", cls224.shape, cls256.shape)
+
+
+ALL = {"dinov2": g_dinov2, "tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
        "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "infer": g_infer, "e2e": g_e2e,
        "encode_file": g_encode_file}
 
