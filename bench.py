@@ -85,10 +85,17 @@ def main() -> None:
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    rank, world, local = cdist.init_from_env("nccl")
+    # RCCL ("nccl") on a real multi-GPU node.  CBAS_DIST_BACKEND=gloo rehearses the multi-rank control
+    # flow on a box with fewer GPUs than ranks (ranks then share devices; the gather goes through host
+    # memory) - a rehearsal, not a measurement.
+    backend = os.environ.get("CBAS_DIST_BACKEND", "nccl")
+    if backend == "nccl" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local = cdist.init_from_env(backend)
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

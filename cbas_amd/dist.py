@@ -53,7 +53,8 @@ def gather_rows(local: Sequence[torch.Tensor], dst: int = 0) -> Optional[List[Li
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return [list(local)]
-    assert len(local) > 0 or True
+    if dist.get_backend() == "gloo":          # gloo moves host memory: stage device tensors through the CPU
+        local = [t.cpu() for t in local]
     ref = local[0] if len(local) else None
     device = ref.device if ref is not None else torch.device("cuda" if dist.get_backend() == "nccl" else "cpu")
     # 1. counts: (max_clips_per_rank,) per rank, -1 padded
@@ -124,6 +125,8 @@ def barrier() -> None:
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
