@@ -166,8 +166,8 @@ class HeadConfig:
         return 2.0 * mac
 
     def validate(self) -> None:
-        if self.lstm_layers != 1:
-            raise NotImplementedError("lstm_layers > 1 is not implemented in the fused head")
+        if not 1 <= self.lstm_layers <= 4:
+            raise NotImplementedError("lstm_layers must be in [1, 4]")
         if not self.use_acceleration:
             raise NotImplementedError("use_acceleration=False is not implemented")
         if self.seq_len < 3:

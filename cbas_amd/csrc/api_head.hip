@@ -18,11 +18,13 @@ struct cbas_head {
     HeadDims d;
     // device weights
     float* wbuf = nullptr;           // one arena
-    const float *w_proj, *b_bott, *ln_w, *ln_b, *b_lin1, *w_lin0, *b_lin0, *w_ih, *b_gate, *w_hh, *w_att, *w_lin2, *b_lin2;
+    const float *w_proj, *b_bott, *ln_w, *ln_b, *b_lin1, *w_lin0, *b_lin0, *w_att, *w_lin2, *b_lin2;
+    int n_layers = 1;
+    const float *w_ih[4], *b_gate[4], *w_hh[4];       // per stacked LSTM layer: [8h][in], [8h], [2][4h][h]
     float b_att, gate_sigmoid, att_temp;
     // workspaces
     float *rows32 = nullptr, *proj = nullptr, *aug = nullptr, *xl = nullptr, *gin = nullptr, *hout = nullptr,
-          *lin_logits = nullptr;
+          *lin_logits = nullptr, *hfull = nullptr;     // hfull: [w][T][2h], inner-layer outputs of a stacked LSTM
     int64_t proj_rows_cap = 0;
 };
 
@@ -30,8 +32,9 @@ namespace {
 
 int64_t head_weights_count(const cbas_head_config& c) {
     const int64_t I = c.in_features, C = c.out_features, Bn = c.bottleneck_dim, L0 = c.lin0_dim, h = c.lstm_hidden_size;
-    return 2 + 3 * (Bn * I + Bn) + 3 * 2 * Bn + (L0 * 3 * Bn + L0) + (C * I + C) + 2 * (4 * h * L0 + 4 * h * h + 8 * h) +
-           (2 * h + 1) + (C * 2 * h + C);
+    int64_t lstm = 0;
+    for (int l = 0; l < c.lstm_layers; ++l) lstm += 2 * (4 * h * (l == 0 ? L0 : 2 * h) + 4 * h * h + 8 * h);
+    return 2 + 3 * (Bn * I + Bn) + 3 * 2 * Bn + (L0 * 3 * Bn + L0) + (C * I + C) + lstm + (2 * h + 1) + (C * 2 * h + C);
 }
 
 // One chunk of windows through expand -> lin0 -> centre -> in-proj -> recurrent -> pool.
@@ -45,11 +48,17 @@ int run_chunk(cbas_head* h, int64_t nw, int sliding, int64_t w0, int64_t r0, int
     g.M = nw * d.T; g.N = d.L0; g.N_alloc = d.L0; g.K = 3 * d.Bn;
     LAUNCH_TRY(launch_gemm_f32(g, 1, st));
     LAUNCH_TRY(launch_head_centre(h->xl, nw, d.T, d.L0, st));
-    Gemm32Params q{};
-    q.A = h->xl; q.lda = d.L0; q.W = h->w_ih; q.bias = h->b_gate; q.out = h->gin; q.ldo = 8 * d.h;
-    q.M = nw * d.T; q.N = 8 * d.h; q.N_alloc = 8 * d.h; q.K = d.L0;
-    LAUNCH_TRY(launch_gemm_f32(q, 0, st));
-    LAUNCH_TRY(launch_head_lstm(h->gin, h->w_hh, d, nw, h->hout, st));
+    for (int l = 0; l < h->n_layers; ++l) {
+        const bool last = l == h->n_layers - 1;
+        Gemm32Params q{};                                   // W_ih x + b_ih + b_hh for both directions as one GEMM
+        q.A = l == 0 ? h->xl : h->hfull; q.lda = l == 0 ? d.L0 : 2 * d.h; q.K = (int)q.lda;
+        q.W = h->w_ih[l]; q.bias = h->b_gate[l]; q.out = h->gin; q.ldo = 8 * d.h;
+        q.M = nw * d.T; q.N = 8 * d.h; q.N_alloc = 8 * d.h;
+        LAUNCH_TRY(launch_gemm_f32(q, 0, st));
+        // inner layers feed the next layer at every time step; only the last one can use the truncated ranges
+        LAUNCH_TRY(launch_head_lstm(h->gin, h->w_hh[l], d, last ? d.lo : 0, last ? d.hi : d.T, nw,
+                                    last ? h->hout : h->hfull, st));
+    }
     LAUNCH_TRY(launch_head_pool(h->hout, h->lin_logits, d, h->w_att, h->b_att, h->att_temp, h->w_lin2, h->b_lin2,
                                 h->gate_sigmoid, temperature, nw, probs, logits, latent, st));
     return CBAS_OK;
@@ -72,7 +81,7 @@ extern "C" void cbas_head_destroy(cbas_head* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {h->wbuf, h->rows32, h->proj, h->aug, h->xl, h->gin, h->hout, h->lin_logits};
+    void* bufs[] = {h->wbuf, h->rows32, h->proj, h->aug, h->xl, h->gin, h->hout, h->lin_logits, h->hfull};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete h;
@@ -91,6 +100,7 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     if (L0 % 32 || L0 <= 0) return cbas_fail(CBAS_EINVAL, "lin0_dim=%lld must be a multiple of 32", (long long)L0);
     if (hh != 64 && hh != 128) return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%lld: only 64 and 128 are built", (long long)hh);
     if (T < 3 || T > 101) return cbas_fail(CBAS_EINVAL, "seq_len=%d outside [3,101]", T);
+    if (c.lstm_layers < 1 || c.lstm_layers > 4) return cbas_fail(CBAS_EINVAL, "lstm_layers=%d outside [1,4]", c.lstm_layers);
     const int hsl = T / 2, sw = c.center_window_size;
     const int lo = hsl - sw > 0 ? hsl - sw : 0, hi = hsl + sw + 1 < T ? hsl + sw + 1 : T;
     if (lo >= hi) return cbas_fail(CBAS_EINVAL, "empty centre window (seq_len=%d, center_window_size=%d)", T, sw);
@@ -119,13 +129,16 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     const float* lin0_b = p; p += L0;
     const float* lin1_w = p; p += C * I;
     const float* lin1_b = p; p += C;
-    const float *wih[2], *whh[2], *bih[2], *bhh[2];
-    for (int dir = 0; dir < 2; ++dir) {
-        wih[dir] = p; p += 4 * hh * L0;
-        whh[dir] = p; p += 4 * hh * hh;
-        bih[dir] = p; p += 4 * hh;
-        bhh[dir] = p; p += 4 * hh;
-    }
+    const int NL = c.lstm_layers;
+    h->n_layers = NL;
+    const float *wih[4][2], *whh[4][2], *bih[4][2], *bhh[4][2];
+    for (int l = 0; l < NL; ++l)
+        for (int dir = 0; dir < 2; ++dir) {
+            wih[l][dir] = p; p += 4 * hh * (l == 0 ? L0 : 2 * hh);
+            whh[l][dir] = p; p += 4 * hh * hh;
+            bih[l][dir] = p; p += 4 * hh;
+            bhh[l][dir] = p; p += 4 * hh;
+        }
     const float* att_w = p; p += 2 * hh;
     const float att_b = *p; p += 1;
     const float* lin2_w = p; p += C * 2 * hh;
@@ -146,11 +159,15 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     const size_t o_blin1 = put(lin1_b, C); pad4();
     const size_t o_wlin0 = put(lin0_w, L0 * 3 * Bn);
     const size_t o_blin0 = put(lin0_b, L0); pad4();
-    const size_t o_wih = arena.size(); put(wih[0], 4 * hh * L0); put(wih[1], 4 * hh * L0);
-    const size_t o_bgate = arena.size();
-    for (int dir = 0; dir < 2; ++dir)
-        for (int64_t i = 0; i < 4 * hh; ++i) arena.push_back(bih[dir][i] + bhh[dir][i]);
-    const size_t o_whh = arena.size(); put(whh[0], 4 * hh * hh); put(whh[1], 4 * hh * hh);
+    size_t o_wih[4], o_bgate[4], o_whh[4];
+    for (int l = 0; l < NL; ++l) {
+        const int64_t in = l == 0 ? L0 : 2 * hh;
+        o_wih[l] = arena.size(); put(wih[l][0], 4 * hh * in); put(wih[l][1], 4 * hh * in);
+        o_bgate[l] = arena.size();
+        for (int dir = 0; dir < 2; ++dir)
+            for (int64_t i = 0; i < 4 * hh; ++i) arena.push_back(bih[l][dir][i] + bhh[l][dir][i]);
+        o_whh[l] = arena.size(); put(whh[l][0], 4 * hh * hh); put(whh[l][1], 4 * hh * hh);
+    }
     const size_t o_watt = put(att_w, 2 * hh); pad4();
     const size_t o_wlin2 = put(lin2_w, C * 2 * hh); pad4();
     const size_t o_blin2 = put(lin2_b, C); pad4();
@@ -173,7 +190,7 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     CREATE_TRY(hipMemcpy(h->wbuf, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
     h->w_proj = h->wbuf + o_proj; h->b_bott = h->wbuf + o_bbott; h->ln_w = h->wbuf + o_lnw; h->ln_b = h->wbuf + o_lnb;
     h->b_lin1 = h->wbuf + o_blin1; h->w_lin0 = h->wbuf + o_wlin0; h->b_lin0 = h->wbuf + o_blin0;
-    h->w_ih = h->wbuf + o_wih; h->b_gate = h->wbuf + o_bgate; h->w_hh = h->wbuf + o_whh;
+    for (int l = 0; l < NL; ++l) { h->w_ih[l] = h->wbuf + o_wih[l]; h->b_gate[l] = h->wbuf + o_bgate[l]; h->w_hh[l] = h->wbuf + o_whh[l]; }
     h->w_att = h->wbuf + o_watt; h->w_lin2 = h->wbuf + o_wlin2; h->b_lin2 = h->wbuf + o_blin2;
 
     h->proj_rows_cap = WCHUNK * T;       // explicit-window mode needs WCHUNK*T rows, sliding WCHUNK+T
@@ -184,6 +201,7 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     CREATE_TRY(hipMalloc(&h->gin, WCHUNK * T * 8 * hh * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->hout, WCHUNK * (hi - lo) * 2 * hh * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->lin_logits, WCHUNK * C * sizeof(float)));
+    if (NL > 1) CREATE_TRY(hipMalloc(&h->hfull, WCHUNK * T * 2 * hh * sizeof(float)));
 #undef CREATE_TRY
     *out = h;
     return CBAS_OK;

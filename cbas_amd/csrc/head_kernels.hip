@@ -281,13 +281,13 @@ int launch_head_centre(float* xl, int64_t n_windows, int T, int L0, hipStream_t 
     return CHECK_LAUNCH();
 }
 
-int launch_head_lstm(const float* gin, const float* w_hh, const HeadDims& d, int64_t n_windows, float* hout,
-                     hipStream_t stream) {
+int launch_head_lstm(const float* gin, const float* w_hh, const HeadDims& d, int olo, int ohi, int64_t n_windows,
+                     float* hout, hipStream_t stream) {
     const dim3 grid((unsigned)((n_windows + 15) / 16), 2);
     if (d.h == 64)
-        hipLaunchKernelGGL(head_lstm_kernel<64>, grid, dim3(256), 0, stream, gin, w_hh, d.T, d.lo, d.hi, n_windows, hout);
+        hipLaunchKernelGGL(head_lstm_kernel<64>, grid, dim3(256), 0, stream, gin, w_hh, d.T, olo, ohi, n_windows, hout);
     else if (d.h == 128)
-        hipLaunchKernelGGL(head_lstm_kernel<128>, grid, dim3(512), 0, stream, gin, w_hh, d.T, d.lo, d.hi, n_windows, hout);
+        hipLaunchKernelGGL(head_lstm_kernel<128>, grid, dim3(512), 0, stream, gin, w_hh, d.T, olo, ohi, n_windows, hout);
     else
         return -1;
     return CHECK_LAUNCH();

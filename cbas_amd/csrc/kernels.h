@@ -108,10 +108,11 @@ int launch_head_expand(const float* proj, const HeadDims& d, const float* b_bott
                        int64_t r0, int64_t n_frames, float* aug, float* lin_logits, hipStream_t stream);
 // xl[w][t][:] -= mean_t xl[w][t][:]
 int launch_head_centre(float* xl, int64_t n_windows, int T, int L0, hipStream_t stream);
-// Recurrent half of the BiLSTM: gin[w][t][dir*4h + gate*h + unit] holds W_ih x + b; runs fwd steps
-// 0..hi-1 and bwd steps T-1..lo, writes hout[w][t-lo][dir*h + unit] for t in [lo,hi).
-int launch_head_lstm(const float* gin, const float* w_hh, const HeadDims& d, int64_t n_windows, float* hout,
-                     hipStream_t stream);
+// Recurrent half of one BiLSTM layer: gin[w][t][dir*4h + gate*h + unit] holds W_ih x + b; runs fwd steps
+// 0..ohi-1 and bwd steps T-1..olo, writes hout[w][t-olo][dir*h + unit] for t in [olo,ohi).  The last
+// layer uses the centre window (olo,ohi) = (lo,hi); inner layers of a stacked LSTM use (0,T).
+int launch_head_lstm(const float* gin, const float* w_hh, const HeadDims& d, int olo, int ohi, int64_t n_windows,
+                     float* hout, hipStream_t stream);
 // attention pooling + lin2 + gate lerp + softmax(logits / max(1e-3, T))
 int launch_head_pool(const float* hout, const float* lin_logits, const HeadDims& d, const float* w_att,
                      float b_att, float att_temp, const float* w_lin2, const float* b_lin2, float gate_sigmoid,

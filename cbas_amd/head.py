@@ -32,8 +32,10 @@ def pack_head_weights(cfg: HeadConfig, w: Mapping[str, np.ndarray]) -> np.ndarra
     for s in ("cls", "delta", "acc"):
         names += [f"{s}_ln.weight", f"{s}_ln.bias"]
     names += ["lin0.0.weight", "lin0.0.bias", "lin1.weight", "lin1.bias"]
-    for sfx in ("", "_reverse"):
-        names += [f"lstm.weight_ih_l0{sfx}", f"lstm.weight_hh_l0{sfx}", f"lstm.bias_ih_l0{sfx}", f"lstm.bias_hh_l0{sfx}"]
+    for layer in range(cfg.lstm_layers):
+        for sfx in ("", "_reverse"):
+            names += [f"lstm.weight_ih_l{layer}{sfx}", f"lstm.weight_hh_l{layer}{sfx}",
+                      f"lstm.bias_ih_l{layer}{sfx}", f"lstm.bias_hh_l{layer}{sfx}"]
     names += ["attention_head.weight", "attention_head.bias", "lin2.weight", "lin2.bias"]
     shapes = head_param_shapes(cfg)
     missing = [n for n in names if n not in w]
@@ -117,7 +119,7 @@ class ClassifierLSTMDeltas:
         cfg = self.config
         self._lib = _lib.load()
         cc = _lib.HeadConfigC(cfg.in_features, cfg.out_features, cfg.seq_len, cfg.bottleneck_dim, cfg.lin0_dim,
-                              cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha)
+                              cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers)
         blob = pack_head_weights(cfg, self._weights)
         need = self._lib.cbas_head_weights_count(C.byref(cc))
         if need != blob.shape[0]:
@@ -176,6 +178,7 @@ def from_reference_module(module, device) -> ClassifierLSTMDeltas:
     sd = module.state_dict()
     h = int(sd["attention_head.weight"].shape[1]) // 2
     m = ClassifierLSTMDeltas(module.in_features, module.out_features, seq_len=module.seq_len,
-                             center_window_size=module.sw, ema_alpha=module.ema_alpha, lstm_hidden_size=h)
+                             center_window_size=module.sw, ema_alpha=module.ema_alpha, lstm_hidden_size=h,
+                             lstm_layers=int(getattr(module.lstm, "num_layers", 1)))
     m.load_state_dict(sd)
     return m.to(device)

@@ -200,11 +200,12 @@ def head_param_shapes(cfg: HeadConfig) -> Dict[str, Tuple[int, ...]]:
     s["lin1.bias"] = (C,)
     s["lin2.weight"] = (C, 2 * h)
     s["lin2.bias"] = (C,)
-    for sfx in ("", "_reverse"):
-        s[f"lstm.weight_ih_l0{sfx}"] = (4 * h, L0)
-        s[f"lstm.weight_hh_l0{sfx}"] = (4 * h, h)
-        s[f"lstm.bias_ih_l0{sfx}"] = (4 * h,)
-        s[f"lstm.bias_hh_l0{sfx}"] = (4 * h,)
+    for layer in range(cfg.lstm_layers):          # nn.LSTM(256, h, num_layers, bidirectional): layer k > 0 reads 2h
+        for sfx in ("", "_reverse"):
+            s[f"lstm.weight_ih_l{layer}{sfx}"] = (4 * h, L0 if layer == 0 else 2 * h)
+            s[f"lstm.weight_hh_l{layer}{sfx}"] = (4 * h, h)
+            s[f"lstm.bias_ih_l{layer}{sfx}"] = (4 * h,)
+            s[f"lstm.bias_hh_l{layer}{sfx}"] = (4 * h,)
     return s
 
 

@@ -49,7 +49,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   2
+#define CBAS_ABI_VERSION   3
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -150,6 +150,7 @@ typedef struct cbas_head_config {
     int32_t lstm_hidden_size;   /* 64 (or 128)                */
     int32_t center_window_size; /* 5                          */
     float   ema_alpha;          /* 0.3                        */
+    int32_t lstm_layers;        /* 1 (stacked BiLSTM layers)  */
 } cbas_head_config;
 
 /* float32 elements expected by cbas_head_create, in this order (state_dict names):
@@ -158,7 +159,8 @@ typedef struct cbas_head_config {
  *   cls_ln.weight[Bn] .bias[Bn]  delta_ln.weight .bias  acc_ln.weight .bias
  *   lin0.0.weight[L0*3Bn] .bias[L0]
  *   lin1.weight[C*I] .bias[C]
- *   lstm.weight_ih_l0[4h*L0] weight_hh_l0[4h*h] bias_ih_l0[4h] bias_hh_l0[4h], then the same four _reverse
+ *   per LSTM layer k = 0..lstm_layers-1 (input width L0 for k = 0, 2h above):
+ *     lstm.weight_ih_lk[4h*in] weight_hh_lk[4h*h] bias_ih_lk[4h] bias_hh_lk[4h], then the same four _reverse
  *   attention_head.weight[2h] .bias[1]
  *   lin2.weight[C*2h] .bias[C]                                                                   */
 int64_t cbas_head_weights_count(const cbas_head_config* cfg);

@@ -92,11 +92,17 @@ def head_forward(x: np.ndarray, w: Dict[str, np.ndarray], seq_len: int = 31, sw:
     xl = (xl - xl.mean(axis=1, keepdims=True, dtype=F32)).astype(F32)
 
     # forward_lstm, :131-148
-    fwd = lstm_direction(xl, w["lstm.weight_ih_l0"], w["lstm.weight_hh_l0"],
-                         w["lstm.bias_ih_l0"], w["lstm.bias_hh_l0"], reverse=False)
-    bwd = lstm_direction(xl, w["lstm.weight_ih_l0_reverse"], w["lstm.weight_hh_l0_reverse"],
-                         w["lstm.bias_ih_l0_reverse"], w["lstm.bias_hh_l0_reverse"], reverse=True)
-    out = np.concatenate([fwd, bwd], axis=-1)
+    # nn.LSTM(num_layers=k, bidirectional=True): layer l > 0 consumes cat(fwd, bwd) of layer l-1
+    out, layer = xl, 0
+    while f"lstm.weight_ih_l{layer}" in w:
+        p = f"lstm.{{}}_l{layer}"
+        fwd = lstm_direction(out, w[p.format("weight_ih")], w[p.format("weight_hh")],
+                             w[p.format("bias_ih")], w[p.format("bias_hh")], reverse=False)
+        r = p + "_reverse"
+        bwd = lstm_direction(out, w[r.format("weight_ih")], w[r.format("weight_hh")],
+                             w[r.format("bias_ih")], w[r.format("bias_hh")], reverse=True)
+        out = np.concatenate([fwd, bwd], axis=-1)
+        layer += 1
     L = out.shape[1]
     l, r = max(0, hsl - sw), min(L, hsl + sw + 1)
     if l >= r:

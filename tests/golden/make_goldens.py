@@ -250,8 +250,9 @@ def ref_head(classifier_head, hcfg: C.HeadConfig, hw):
 
 def g_head(out):
     _, classifier_head = import_reference()
-    for tag, h, C_, I in (("h64", 64, 9, 768), ("h128", 128, 5, 768), ("h64_d384", 64, 9, 384)):
-        hcfg = C.HeadConfig(in_features=I, out_features=C_, lstm_hidden_size=h)
+    for tag, h, C_, I, nl in (("h64", 64, 9, 768, 1), ("h128", 128, 5, 768, 1), ("h64_d384", 64, 9, 384, 1),
+                              ("h64_l2", 64, 9, 768, 2)):           # stacked BiLSTM (sweep_runner.py:108 lists [1, 2])
+        hcfg = C.HeadConfig(in_features=I, out_features=C_, lstm_hidden_size=h, lstm_layers=nl)
         hw = W.synth_head_weights(hcfg, HEAD_SEED)
         m = ref_head(classifier_head, hcfg, hw)
         seq = synth.cls_walk(21, 64 + 30, I).astype(np.float32)

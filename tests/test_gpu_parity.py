@@ -157,12 +157,13 @@ def test_vitb_full_batch_invariance():
         enc.close()
 
 
-@pytest.mark.parametrize("tag,h,ncls,dim", [("h64", 64, 9, 768), ("h128", 128, 5, 768), ("h64_d384", 64, 9, 384)])
-def test_head_forward_goldens(golden_dir, tag, h, ncls, dim):
+@pytest.mark.parametrize("tag,h,ncls,dim,nl", [("h64", 64, 9, 768, 1), ("h128", 128, 5, 768, 1),
+                                               ("h64_d384", 64, 9, 384, 1), ("h64_l2", 64, 9, 768, 2)])
+def test_head_forward_goldens(golden_dir, tag, h, ncls, dim, nl):
     from cbas_amd.head import ClassifierLSTMDeltas
     g = load(golden_dir, f"head_{tag}")
-    hc = C.HeadConfig(in_features=dim, out_features=ncls, lstm_hidden_size=h)
-    m = ClassifierLSTMDeltas(dim, ncls, lstm_hidden_size=h)
+    hc = C.HeadConfig(in_features=dim, out_features=ncls, lstm_hidden_size=h, lstm_layers=nl)
+    m = ClassifierLSTMDeltas(dim, ncls, lstm_hidden_size=h, lstm_layers=nl)
     m.load_state_dict(W.synth_head_weights(hc, 4321))
     m.to("cuda")
     assert next(m.parameters()).device.type == "cuda"

@@ -67,7 +67,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     loaded = _lib.load()
-    assert loaded.cbas_abi_version() == 2
+    assert loaded.cbas_abi_version() == 3
 
 
 def test_weight_counts_agree_between_host_and_library():
@@ -77,19 +77,29 @@ def test_weight_counts_agree_between_host_and_library():
     cfg = Cfg.VIT_TINY
     blob = pack_encoder_weights(cfg, W.synth_encoder_weights(cfg, 1))
     cc = _lib.EncConfig(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
-                        cfg.num_register_tokens, 16, 1e-5, 100.0, 8, 64, 64, 0)
+                        cfg.num_register_tokens, 16, 1e-5, 100.0, 8, 64, 64, 0, 1, 0)
     assert lib.cbas_enc_weights_count(C.byref(cc)) == blob.shape[0]
+    v2 = Cfg.DINOV2_REG_TINY                              # position embedding + key bias in the blob
+    blob2 = pack_encoder_weights(v2, W.synth_encoder_weights(v2, 1))
+    cc2 = _lib.EncConfig(v2.hidden_size, v2.intermediate_size, v2.num_hidden_layers, v2.num_attention_heads,
+                         v2.num_register_tokens, 14, 1e-6, 100.0, 8, 70, 70, 0, 0, v2.pos_embed_grid)
+    assert lib.cbas_enc_weights_count(C.byref(cc2)) == blob2.shape[0]
+    hc2 = Cfg.HeadConfig(lstm_layers=2)
+    hb2 = pack_head_weights(hc2, W.synth_head_weights(hc2, 2))
+    hcc2 = _lib.HeadConfigC(hc2.in_features, hc2.out_features, hc2.seq_len, hc2.bottleneck_dim, hc2.lin0_dim,
+                            hc2.lstm_hidden_size, hc2.center_window_size, hc2.ema_alpha, 2)
+    assert lib.cbas_head_weights_count(C.byref(hcc2)) == hb2.shape[0]
     for h in (64, 128):
         hc = Cfg.HeadConfig(lstm_hidden_size=h, out_features=7)
         hb = pack_head_weights(hc, W.synth_head_weights(hc, 2))
         hcc = _lib.HeadConfigC(hc.in_features, hc.out_features, hc.seq_len, hc.bottleneck_dim, hc.lin0_dim,
-                               hc.lstm_hidden_size, hc.center_window_size, hc.ema_alpha)
+                               hc.lstm_hidden_size, hc.center_window_size, hc.ema_alpha, 1)
         assert lib.cbas_head_weights_count(C.byref(hcc)) == hb.shape[0]
 
 
 def test_create_rejects_bad_arguments_without_gpu():
     lib = _lib.load()
-    cc = _lib.EncConfig(100, 400, 2, 2, 4, 16, 1e-5, 100.0, 8, 64, 64, 0)      # hidden_size not /128
+    cc = _lib.EncConfig(100, 400, 2, 2, 4, 16, 1e-5, 100.0, 8, 64, 64, 0, 1, 0)      # hidden_size not /128
     h = C.c_void_p()
     dummy = np.zeros(4, np.float32)
     rc = lib.cbas_enc_create(C.byref(cc), dummy.ctypes.data, 4, 0, C.byref(h))

@@ -70,10 +70,11 @@ def test_rope_table_matches_reference_shape():
     assert abs(float(cos[0, 0]) - np.cos(2 * np.pi * (2 * (0.5 / 14) - 1))) < 1e-6
 
 
-@pytest.mark.parametrize("tag,h,ncls,dim", [("h64", 64, 9, 768), ("h128", 128, 5, 768), ("h64_d384", 64, 9, 384)])
-def test_head_goldens(golden_dir, tag, h, ncls, dim):
+@pytest.mark.parametrize("tag,h,ncls,dim,nl", [("h64", 64, 9, 768, 1), ("h128", 128, 5, 768, 1),
+                                               ("h64_d384", 64, 9, 384, 1), ("h64_l2", 64, 9, 768, 2)])
+def test_head_goldens(golden_dir, tag, h, ncls, dim, nl):
     g = load(golden_dir, f"head_{tag}")
-    hc = C.HeadConfig(in_features=dim, out_features=ncls, lstm_hidden_size=h)
+    hc = C.HeadConfig(in_features=dim, out_features=ncls, lstm_hidden_size=h, lstm_layers=nl)
     hw = W.synth_head_weights(hc, 4321)
     seq = synth.cls_walk(21, 94, dim).astype(np.float32)
     x = np.stack([seq[i:i + 31] for i in range(64)])
