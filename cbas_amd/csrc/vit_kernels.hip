@@ -175,11 +175,17 @@ __device__ __forceinline__ int v_off(int row, int col) {   // col in halves
     return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
 }
 
-template <int NKT>
+// NKT = key tiles held in LDS (even); NV = tiles that contain at least one real key when that is known
+// at compile time (T in ((NV-1)*16, NV*16]), 0 = decide per element at run time.  With NV fixed only the
+// ONE partial tile is masked (4 compares per lane, once) and fully padded tiles cost no MFMA; the
+// run-time form costs a compare+select per score because hipcc if-converts the tail test.
+template <int NKT, int NV>
 __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
-                                                           int T, int D, int n_heads) {
+                                                                            int T, int D, int n_heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWS = NKT * 16, NG = NKT / 2;
+    constexpr int ROWS = NKT * 16;
+    constexpr int NQK = NV ? NV : NKT;                 // key tiles that need S = K Q^T
+    constexpr int NG = NV ? (NV + 1) / 2 : NKT / 2;    // 32-key groups that need P.V
     char* Ks = smem;
     char* Vs = smem + ROWS * 128;
 
@@ -215,32 +221,42 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
     }
     __syncthreads();
 
+    // Per-lane base addresses: the swizzles depend on (row & 15) / (row & 7) only, tile strides are
+    // multiples of 16 rows, so every fragment read below is base + compile-time immediate.
+    const char* kb0 = Ks + k_off(li, g);               // + kt*2048 for key tile kt, k-half 0
+    const char* kb1 = Ks + k_off(li, 4 + g);           //                             k-half 1
+    const char* vb[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vb[dt] = Vs + v_off(4 * g + (li >> 2), 16 * dt + 4 * (li & 3));   // + s2*4096 (+2048)
+    float tail_bias[4];                                // 0 / -inf for the single partial tile (NV fixed)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tail_bias[r] = (NV && (NV - 1) * 16 + 4 * g + r >= T) ? -INFINITY : 0.f;
+
     for (; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + li;
         if (qt + nwaves < nqt) load_q(qt + nwaves, qn);          // next tile's Q under this tile's math
 
         // ---- S^T = K Q^T, two key tiles (4 fragment reads, 4 MFMAs) per group; the scheduling
-        // barriers keep the compiler from hoisting all 2*NKT fragment reads (4 VGPRs each) up front
-        f32x4 s[NKT];
+        // barriers keep the compiler from hoisting every fragment read (4 VGPRs each) up front
+        f32x4 s[NQK];
 #pragma unroll
-        for (int grp = 0; grp < NG; ++grp) {
-            f16x8 kf[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                kf[u] = *reinterpret_cast<const f16x8*>(Ks + k_off((2 * grp + (u >> 1)) * 16 + li, (u & 1) * 4 + g));
+        for (int grp = 0; grp < (NQK + 1) / 2; ++grp) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                const int kt = 2 * grp + u;
+                if (kt >= NQK) continue;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * u], qf[0], acc, 0, 0, 0);
-                s[2 * grp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * u + 1], qf[1], acc, 0, 0, 0);
+                if (NV && kt == NV - 1) acc = f32x4{tail_bias[0], tail_bias[1], tail_bias[2], tail_bias[3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(kb0 + kt * 2048), qf[0], acc, 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(kb1 + kt * 2048), qf[1], acc, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // s[kt][r] = S[q][key = kt*16 + 4g + r]   (q already carries the 1/8 scale)
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt * 16 + 16 > T) {                                  // only the tail tile(s) hold padding keys
+        for (int kt = 0; kt < NQK; ++kt) {
+            if (!NV) {                                             // run-time tail: per-element select
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
@@ -254,11 +270,11 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
         f16x8 pf[NG];                                                // P^T packed as the B operand of P.V
 #pragma unroll
         for (int grp = 0; grp < NG; ++grp) {
-            f32x4 e0, e1;
+            f32x4 e0, e1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 e0[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp][r], 1.4426950408889634f, -m2));
-                e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1][r], 1.4426950408889634f, -m2));
+                if (2 * grp + 1 < NQK) e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1 < NQK ? 2 * grp + 1 : 0][r], 1.4426950408889634f, -m2));
             }
             sum += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
             pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
@@ -272,15 +288,13 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < NG; ++s2) {
-            const int krow = 32 * s2 + 4 * g + (li >> 2);
             f16x8 vf[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int col = 16 * dt + 4 * (li & 3);
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow, col)));
+                    (__attribute__((address_space(3))) s16x4*)(vb[dt] + s2 * 4096));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow + 16, col)));
+                    (__attribute__((address_space(3))) s16x4*)(vb[dt] + s2 * 4096 + 2048));
                 union { struct { s16x4 a, b; } s; f16x8 v; } u;
                 u.s.a = lo; u.s.b = hi;
                 vf[dt] = u.v;
@@ -428,20 +442,21 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
     }
 }
 
-template <int NKT>
+template <int NKT, int NV>
 int launch_attention_t(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
     constexpr int lds = NKT * 16 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT, NV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
     // at most 8 waves (a 1024-thread bound caps the kernel at 128 VGPRs and it spills); the fewest waves that keep
     // every wave equally loaded: T = 201 -> 13 tiles -> 7 waves x 2, T = 261 -> 17 tiles -> 6 waves x 3
-    const int nqt = (T + 15) / 16, rounds = (nqt + 7) / 8, nwaves = (nqt + rounds - 1) / rounds;
-    hipLaunchKernelGGL((attention_kernel<NKT>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, out, T, D, n_heads);
+    constexpr int maxw = 8;                  // measured: 13 waves x 1 tile (35 us) loses to 7 waves x 2 tiles (29.6 us) at T = 201
+    const int nqt = (T + 15) / 16, rounds = (nqt + maxw - 1) / maxw, nwaves = (nqt + rounds - 1) / rounds;
+    hipLaunchKernelGGL((attention_kernel<NKT, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, out, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -536,10 +551,14 @@ int launch_final_norm_cls(const float* x, const float* gamma, const float* beta,
 
 int launch_attention(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
     const int nkt = (T + 15) / 16;
-    if (nkt <= 2) return launch_attention_t<2>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 6) return launch_attention_t<6>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 14) return launch_attention_t<14>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 18) return launch_attention_t<18>(qkv, out, n, T, D, n_heads, stream);
+    // exact-tile-count instantiations for the sequence lengths CBAS produces: 224x224 /16 -> T = 201 (13 tiles),
+    // 256x256 /16 and 224x224 /14 -> T = 261 (17 tiles); everything else takes the run-time-masked form
+    if (nkt == 13) return launch_attention_t<14, 13>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt == 17) return launch_attention_t<18, 17>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 2) return launch_attention_t<2, 0>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 6) return launch_attention_t<6, 0>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 14) return launch_attention_t<14, 0>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt <= 18) return launch_attention_t<18, 0>(qkv, out, n, T, D, n_heads, stream);
     // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
     const int nqb = ((T + 15) / 16 + 7) / 8;
     hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, out, T, D, n_heads);
