@@ -52,10 +52,10 @@ __device__ __forceinline__ f16x8 read_frag(const char* lds_tile, int row, int ch
 // Workgroup tile = (64*WM) x (64*WN), one 64x64 sub-tile per wave.  The larger tiles exist because
 // at 128x128 the kernel stages 1 byte per 64 FLOP from L2 / Infinity Cache into LDS, which caps it
 // near the measured L2->LDS rate; 256x256 halves that traffic.
-template <int EPI, int NSPLIT, int WM, int WN>
+template <int EPI, int NSPLIT, int WM, int WN, int TM = 4>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int BM = 16 * TM * WM, BN = 64 * WN, NW = WM * WN;      // each wave owns (16*TM) rows x 64 columns
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int BUF_BYTES = A_BYTES + B_BYTES * NSPLIT;
 
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk = p.K / BK;
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -107,13 +107,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
         const char* Wt = At + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            f16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = read_frag(At, wr * 64 + i * 16 + frow, kk * 4 + fchunk);
+            f16x8 a[TM], b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = read_frag(Wt, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i) a[i] = read_frag(At, wr * TM * 16 + i * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[j] = read_frag(Wl, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
 
     if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
     // ---- epilogue: lane owns row m (per i) and 4 consecutive columns in each of the 4 n-tiles ---
-    gemm_epilogue_tile<EPI, 4>(p, row0 + wr * 64, col0 + wc * 64, lane, acc, smem + wave * 8192);
+    gemm_epilogue_tile<EPI, TM>(p, row0 + wr * TM * 16, col0 + wc * 64, lane, acc, smem + wave * 8192);
     if (p.stamps && tid == 0) {       // diagnostic builds only: block timeline (start, prologue, loop, end)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
@@ -142,21 +142,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
     }
 }
 
-template <int EPI, int NSPLIT, int WM, int WN>
+template <int EPI, int NSPLIT, int WM, int WN, int TM = 4>
 int launch_one(const GemmParams& p, hipStream_t stream) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 16 * TM * WM, BN = 64 * WN;
     constexpr int lds = 2 * (BM * 128 + BN * 128 * NSPLIT);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;   // per-instantiation; idempotent, racing callers set the same value
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<EPI, NSPLIT, WM, WN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<EPI, NSPLIT, WM, WN, TM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
     if (p.N % BN) return -1;
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_f16_kernel<EPI, NSPLIT, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, NSPLIT, WM, WN, TM>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -172,6 +172,7 @@ int launch_epi(const GemmParams& p, int tile, hipStream_t stream) {
         case GEMM_TILE_256x128: return launch_one<EPI, 1, 4, 2>(p, stream);
         case GEMM_TILE_128x256: return launch_one<EPI, 1, 2, 4>(p, stream);
         case GEMM_TILE_192x256: return launch_one<EPI, 1, 3, 4>(p, stream);
+        case 12: return launch_one<EPI, 1, 2, 4, 8>(p, stream);      // 256x256, 8 waves x (128x64): experiment
         default: return launch_one<EPI, 1, 2, 2>(p, stream);
     }
 }
