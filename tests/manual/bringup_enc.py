@@ -2,7 +2,7 @@
 then CLS parity on the committed goldens.  Run on the GPU box: python scripts/bringup_enc.py"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cbas_amd import config as C, weights as W, synth, _lib
 from cbas_amd.encoder import DinoEncoder
 from oracle import vit_oracle as V
@@ -41,7 +41,7 @@ g = torch.from_numpy(V.preprocess_green(fr)).cuda()
 print("tiny cls f32", rel(enc(g.unsqueeze(1)).squeeze(1).cpu().numpy(), ref[:, 0]))
 enc.close()
 
-gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden")
 for name, cfgname, hw in (("vits16_224", "vits16", 224), ("vitb16_224", "vitb16", 224), ("vitb16_256", "vitb16", 256),
                           ("vitb16_224_noise", "vitb16", 224), ("vitl16_224", "vitl16", 224)):
     g = np.load(os.path.join(gold, name + ".npz"))

@@ -1,10 +1,10 @@
 """GPU bring-up of the classifier head against the goldens made from the reference module."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cbas_amd import config as C, weights as W, synth
 from cbas_amd.head import ClassifierLSTMDeltas
-gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden")
 for tag, h, C_, I in (("h64", 64, 9, 768), ("h128", 128, 5, 768), ("h64_d384", 64, 9, 384)):
     g = np.load(os.path.join(gold, f"head_{tag}.npz"))
     hc = C.HeadConfig(in_features=I, out_features=C_, lstm_hidden_size=h)
