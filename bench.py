@@ -34,7 +34,7 @@ from cbas_amd import dist as cdist  # noqa: E402
 from cbas_amd import weights as W  # noqa: E402
 from cbas_amd import synth  # noqa: E402
 
-METRIC = "frames/sec DINOv3-B/16 224px encode+LSTM classify"
+METRIC = "frames/sec DINOv3-B/16 224px encode+LSTM classify, 1/2/4/8 MI355X"     # BASELINE.json "metric", verbatim
 MFMA_F16_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 BEHAVIORS = 9
 SEQ_LEN = 31

@@ -181,6 +181,8 @@ int launch_epi(const GemmParams& p, int tile, hipStream_t stream) {
 // halve the L2->LDS traffic but quantise worse; costs are relative per-round times measured on
 // MI355X with scripts/gemm_tiles.py.
 int pick_tile(const GemmParams& p) {
+    static const int forced_longk = [] { const char* e = getenv("CBAS_GEMM_TILE_LONGK"); return e ? atoi(e) : 0; }();
+    if (forced_longk && p.K >= 2048) return forced_longk;          // experiments on the down projection only
     static const int forced = [] { const char* e = getenv("CBAS_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
     if (p.tile) return p.tile;
