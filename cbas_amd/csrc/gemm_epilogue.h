@@ -137,10 +137,11 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
         const int sec = (EPI == EPI_QKV) ? head_col0 / p.D : 2;
         const float qs = (sec == 0) ? 0.125f : 1.0f;
 #pragma unroll
-        for (int half = 0; half < TM / 4; ++half) {                    // 64 rows per pass (8 KiB of scratch)
+        for (int half = 0; half < (TM + 3) / 4; ++half) {              // up to 64 rows per pass (8 KiB of scratch)
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = half * 4 + ii;
+                if (i >= TM) break;                                     // compile-time after unrolling (TM = 6: 4 + 2 slabs)
                 f32x4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
@@ -183,6 +184,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
+                if (it * 8 >= (TM - half * 4) * 16) break;              // rows of this pass (compile-time)
                 const int r = it * 8 + (lane >> 3), c = lane & 7;      // 8 rows x 128 bytes per wave store
                 const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = row_base + half * 64 + r;

@@ -1,0 +1,248 @@
+// fp16 MFMA GEMM, "ping-pong" schedule: (32*TMH*2) x 256 x 64 tile, 8 waves as 2(M) x 4(N), each wave
+// (32*TMH) x 64 of C (TMH = 4: 256x256 tile, TMH = 3: 192x256).  Same arithmetic, operand layout, LDS
+// image and fused epilogues as gemm_f16.hip (bit-identical results: every accumulator sees the same
+// MFMAs in the same k order); what differs is the K loop:
+//
+//  * Per-wave tile (32*TMH) x 64 instead of 64 x 64: 24 ds_read_b128 per 64 MFMAs (16 per 32 before),
+//    so the LDS array is no longer a co-limiter of the MFMA pipe.
+//  * The two wave groups (wr = 0 / 1; one wave of each per SIMD) run one barrier apart: while one
+//    group issues its 16-MFMA cluster the other reads fragments and issues LDS-DMA for a later
+//    K-tile, then they swap.  A K-tile is four such phases (one C quadrant of the wave each).
+//  * LDS-DMA is never drained inside the loop: each K-tile is staged as four 16 KiB sub-tiles
+//    (B-sub0, A-sub0, B-sub1, A-sub1: the rows the phase-1/2/3 fragment reads touch), three
+//    sub-tiles stay in flight across the barriers (s_waitcnt vmcnt(6), raw s_barrier), and a
+//    sub-tile region is re-staged only after every read of it has been retired (see the table).
+//
+//  phase of K-tile t (buffer b = t&1)   fragment reads          LDS-DMA issued           MFMA quadrant
+//    P1                                 B-sub0 (4), A-sub0 (8)   A-sub1(t+1) -> b^1        (A0,B0)
+//    P2                                 B-sub1 (4)               B-sub0(t+2) -> b          (A0,B1)
+//    P3                                 A-sub1 (8)               A-sub0(t+2) -> b          (A1,B1)
+//    P4                                 -                        B-sub1(t+2) -> b, vmcnt   (A1,B0)
+//  RAW: a K-tile's data is waited for (counted vmcnt by each issuing wave) before P4's first barrier
+//  of the previous K-tile and first read in P1, i.e. after two further barriers - one more than the
+//  group stagger.  WAR: B-sub0 is re-staged one phase after its reads, which P1 retires with
+//  lgkmcnt(8) before its first barrier (reads issue B first); every other region two phases after.
+//
+// Reference arithmetic replaced: the same nn.Linear calls as gemm_f16.hip ([tf] modeling_dinov3_vit.py
+// :307-309, :331, :356-357).
+#include <stdlib.h>
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ f16x8 read_frag8(const char* lds_tile, int off) {
+    return *reinterpret_cast<const f16x8*>(lds_tile + off);
+}
+
+template <int EPI, int TMH>
+__global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WROWS = 32 * TMH;                  // rows of C per wave
+    constexpr int BM = 2 * WROWS, BN = 256;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_PIECES = 4 * TMH;                // 8-row pieces per A sub-tile (both wave rows)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tiles_n = p.N / BN;
+    const int bid = gemm_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nk = p.K / BK;                          // even, >= 2 (checked by the launcher)
+
+    // ---- LDS-DMA source offsets: two 8-row pieces per wave and sub-tile --------------------------
+    // A-sub h = rows {wr' * WROWS + h * 16*TMH + [0, 16*TMH)}, wr' = 0,1;  B-sub h = rows with bit 5 == h.
+    // piece q of a sub-tile (q = wave, wave + 8); for TMH = 3 there are 12 A pieces: q is clamped, the
+    // duplicates rewrite identical bytes (keeps the per-wave DMA count, and so the vmcnt immediates, uniform)
+    const int lrow = lane >> 3;
+    int a_lds[2][2], b_lds[2][2];
+    unsigned a_src[2][2], b_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            int q = wave + 8 * s;
+            q = q < A_PIECES ? q : A_PIECES - 1;
+            const int ar = (q / (2 * TMH)) * WROWS + h * (16 * TMH) + (q % (2 * TMH)) * 8;   // first row of the piece
+            a_lds[h][s] = ar * 128;
+            const int r = ar + lrow;
+            int grow = row0 + r;
+            grow = grow < p.M_pad - 1 ? grow : p.M_pad - 1;
+            a_src[h][s] = (unsigned)grow * (unsigned)p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+            const int qb = wave + 8 * s;
+            const int br = (((qb >> 2) << 3) | (h << 2) | (qb & 3)) * 8;
+            b_lds[h][s] = A_BYTES + br * 128;
+            const int rb = br + lrow;
+            b_src[h][s] = (unsigned)(col0 + rb) * (unsigned)p.K + (((lane & 7) ^ ((rb >> 1) & 7)) << 3);
+        }
+    // which: 0 = B-sub0, 1 = A-sub0, 2 = B-sub1, 3 = A-sub1 (the issue order within a K-tile)
+    auto stage = [&](int buf, int kt, int which) {
+        char* base = smem + buf * BUF_BYTES;
+        const int h = which >> 1;
+        if (which & 1) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + a_src[h][s] + kt * BK), LDS_PTR(base + a_lds[h][s]), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                __builtin_amdgcn_global_load_lds(GLB_PTR(p.W + b_src[h][s] + kt * BK), LDS_PTR(base + b_lds[h][s]), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (swizzled 128-B rows, as gemm_f16.hip) -------------------------------
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int a_off[2], b_off[2];                           // per k-half; + row-block immediates
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((kk * 4 + fchunk) ^ ((frow >> 1) & 7)) << 4;
+        a_off[kk] = (wr * WROWS + frow) * 128 + sw;
+        b_off[kk] = A_BYTES + (wc * 64 + frow) * 128 + sw;
+    }
+
+    f32x4 acc[2 * TMH][4];
+#pragma unroll
+    for (int i = 0; i < 2 * TMH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+
+    // ---- prologue: K-tile 0 and three sub-tiles of K-tile 1 ------------------------------------
+    stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3);
+    stage(1, 1, 0); stage(1, 1, 1); stage(1, 1, 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
+
+    f16x8 a[TMH][2], b0[2][2], b1[2][2];
+
+#define CBAS_SEG_BARRIER()                      \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
+    auto mfma_quadrant = [&](int ha, f16x8 (&bf)[2][2], int hb) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < TMH; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha * TMH + i][hb * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], a[i][kk], acc[ha * TMH + i][hb * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto read_a = [&](const char* buf, int h) {
+#pragma unroll
+        for (int i = 0; i < TMH; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) a[i][kk] = read_frag8(buf, a_off[kk] + (h * TMH + i) * 2048);
+    };
+    auto read_b = [&](const char* buf, int h, f16x8 (&bf)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bf[j][kk] = read_frag8(buf, b_off[kk] + (h * 2 + j) * 2048);
+    };
+
+    auto ktile = [&](int b, int t) {
+        const char* buf = smem + b * BUF_BYTES;
+        // P1
+        read_b(buf, 0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, 0);
+        if (t + 1 < nk) stage(b ^ 1, t + 1, 3);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 4 B-sub0 reads (issued first) are retired
+        CBAS_SEG_BARRIER();
+        mfma_quadrant(0, b0, 0);
+        CBAS_SEG_BARRIER();
+        // P2
+        read_b(buf, 1, b1);
+        if (t + 2 < nk) stage(b, t + 2, 0);
+        CBAS_SEG_BARRIER();
+        mfma_quadrant(0, b1, 1);
+        CBAS_SEG_BARRIER();
+        // P3
+        read_a(buf, 1);
+        if (t + 2 < nk) stage(b, t + 2, 1);
+        CBAS_SEG_BARRIER();
+        mfma_quadrant(1, b1, 1);
+        CBAS_SEG_BARRIER();
+        // P4
+        if (t + 2 < nk) {
+            stage(b, t + 2, 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // K-tile t+1 has landed; 3 sub-tiles of t+2 in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        CBAS_SEG_BARRIER();
+        mfma_quadrant(1, b0, 0);
+        CBAS_SEG_BARRIER();
+    };
+
+    for (int t = 0; t < nk; t += 2) {
+        ktile(0, t);
+        ktile(1, t + 1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the groups: every wave has now left the loop
+#undef CBAS_SEG_BARRIER
+
+    if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+    gemm_epilogue_tile<EPI, 2 * TMH>(p, row0 + wr * WROWS, col0 + wc * 64, lane, acc, smem + wave * 8192);
+    if (p.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+template <int EPI, int TMH>
+int launch_8ph(const GemmParams& p, hipStream_t stream) {
+    constexpr int BM = 64 * TMH, BN = 256;
+    constexpr int lds = 2 * (BM * 128 + BN * 128);
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static_assert(lds >= 8 * 8192, "epilogue scratch");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_8ph_kernel<EPI, TMH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TMH>), dim3(grid), dim3(512), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int EPI>
+int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
+    if (tile == GEMM_TILE_PP_192x256) return launch_8ph<EPI, 3>(p, stream);
+    return launch_8ph<EPI, 4>(p, stream);
+}
+
+}  // namespace
+
+int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
+    // 32-bit element offsets into A / W; K-tiles are consumed in pairs
+    if (p.W_lo || p.N % 256 || p.K % (2 * BK) || (long long)p.M_pad * p.K >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31))
+        return -1;
+    switch (epi) {
+        case EPI_PATCH: return launch_8ph_epi<EPI_PATCH>(p, tile, stream);
+        case EPI_QKV:   return launch_8ph_epi<EPI_QKV>(p, tile, stream);
+        case EPI_RESID: return launch_8ph_epi<EPI_RESID>(p, tile, stream);
+        case EPI_GELU:  return launch_8ph_epi<EPI_GELU>(p, tile, stream);
+    }
+    return -1;
+}

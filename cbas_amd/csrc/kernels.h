@@ -17,7 +17,9 @@ enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2
                 GEMM_TILE_256x256 = 4,
                 GEMM_TILE_RING_FIRST = 5,       // gemm_f16_ring.hip: 4-deep LDS ring, counted vmcnt
                 GEMM_TILE_RING_256x256_W16 = 5, GEMM_TILE_RING_256x256_W8 = 6,
-                GEMM_TILE_192x256 = 7 };
+                GEMM_TILE_192x256 = 7,
+                GEMM_TILE_PP_256x256 = 13,      // gemm_f16_8ph.hip: 8 waves, ping-pong phases, counted vmcnt
+                GEMM_TILE_PP_192x256 = 14 };
 
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)
@@ -49,6 +51,7 @@ struct GemmParams {
 
 int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_ring(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
+int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // ViT element-wise / attention kernels
