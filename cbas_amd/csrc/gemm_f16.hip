@@ -196,13 +196,13 @@ int pick_tile(const GemmParams& p) {
         if (t256 >= 120) {
             // one workgroup per CU for both: time ~ rounds over the 256 CUs x tile rows
             const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
-            // the 8-wave ping-pong kernel (gemm_f16_8ph.hip) computes the same tile bit-identically and
+            // the 8-wave ping-pong kernel (gemm_f16_8ph.hip) computes the same tiles bit-identically and
             // is 4-8 % faster on every projection; it consumes K-tiles in pairs and uses 32-bit offsets
             static const bool pp_off = [] { const char* e = getenv("CBAS_GEMM_PP"); return e && atoi(e) == 0; }();
             const bool pp = !pp_off && p.K % 128 == 0 && (long long)p.M_pad * p.K < (1ll << 31) &&
                             (long long)p.N * p.K < (1ll << 31);
-            if (c192 < c256) return pp ? GEMM_TILE_PP_192x256 : GEMM_TILE_192x256;
-            return pp ? GEMM_TILE_PP_256x256 : GEMM_TILE_256x256;
+            if (pp) return GEMM_TILE_PP_AUTO;          // its planner also knows 160-row tiles and 128-row tails
+            return c192 < c256 ? GEMM_TILE_192x256 : GEMM_TILE_256x256;
         }
     }
     return GEMM_TILE_128x128;
@@ -213,7 +213,7 @@ int pick_tile(const GemmParams& p) {
 static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
     if (tile == GEMM_TILE_RING_256x256_W16 || tile == GEMM_TILE_RING_256x256_W8 || (tile >= 8 && tile <= 11))
         return launch_gemm_ring(epi, p, tile, stream);
-    if (tile == GEMM_TILE_PP_256x256 || tile == GEMM_TILE_PP_192x256) return launch_gemm_8ph(epi, p, tile, stream);
+    if (tile >= GEMM_TILE_PP_256x256 && tile <= GEMM_TILE_PP_AUTO) return launch_gemm_8ph(epi, p, tile, stream);
     switch (epi) {
         case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
         case EPI_QKV:   return launch_epi<EPI_QKV>(p, tile, stream);

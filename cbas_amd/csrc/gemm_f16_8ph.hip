@@ -1,63 +1,76 @@
-// fp16 MFMA GEMM, "ping-pong" schedule: (32*TMH*2) x 256 x 64 tile, 8 waves as 2(M) x 4(N), each wave
-// (32*TMH) x 64 of C (TMH = 4: 256x256 tile, TMH = 3: 192x256).  Same arithmetic, operand layout, LDS
-// image and fused epilogues as gemm_f16.hip (bit-identical results: every accumulator sees the same
-// MFMAs in the same k order); what differs is the K loop:
+// fp16 MFMA GEMM, "ping-pong" schedule: BM x 256 x 64 tile, 8 waves as 2(M) x 4(N), each wave
+// 16*(TA+TB) rows x 64 columns of C.  (TA,TB) = (4,4): 256x256 tile, (3,3): 192x256, (3,2): 160x256,
+// (2,2): 128x256.  Same arithmetic, operand layout, LDS image and fused epilogues as gemm_f16.hip
+// (bit-identical results: every accumulator sees the same MFMAs in the same k order); what differs
+// is the K loop:
 //
-//  * Per-wave tile (32*TMH) x 64 instead of 64 x 64: 24 ds_read_b128 per 64 MFMAs (16 per 32 before),
+//  * Per-wave tile up to 128 x 64 instead of 64 x 64: 24 ds_read_b128 per 64 MFMAs (16 per 32 before),
 //    so the LDS array is no longer a co-limiter of the MFMA pipe.
 //  * The two wave groups (wr = 0 / 1; one wave of each per SIMD) run one barrier apart: while one
-//    group issues its 16-MFMA cluster the other reads fragments and issues LDS-DMA for a later
-//    K-tile, then they swap.  A K-tile is four such phases (one C quadrant of the wave each).
-//  * LDS-DMA is never drained inside the loop: each K-tile is staged as four 16 KiB sub-tiles
-//    (B-sub0, A-sub0, B-sub1, A-sub1: the rows the phase-1/2/3 fragment reads touch), three
-//    sub-tiles stay in flight across the barriers (s_waitcnt vmcnt(6), raw s_barrier), and a
-//    sub-tile region is re-staged only after every read of it has been retired (see the table).
+//    group issues its MFMA cluster the other reads fragments and issues LDS-DMA for a later K-tile,
+//    then they swap.  A K-tile is four such phases (one C quadrant of the wave each).
+//  * LDS-DMA is never drained inside the loop: each K-tile is staged as four sub-tiles (B-sub0,
+//    A-sub0, B-sub1, A-sub1: the rows the phase-1/2/3 fragment reads touch), three sub-tiles stay
+//    in flight across the barriers (s_waitcnt vmcnt(6), raw s_barrier), and a sub-tile region is
+//    re-staged only after every read of it has been retired (see the table).
 //
-//  phase of K-tile t (buffer b = t&1)   fragment reads          LDS-DMA issued           MFMA quadrant
-//    P1                                 B-sub0 (4), A-sub0 (8)   A-sub1(t+1) -> b^1        (A0,B0)
-//    P2                                 B-sub1 (4)               B-sub0(t+2) -> b          (A0,B1)
-//    P3                                 A-sub1 (8)               A-sub0(t+2) -> b          (A1,B1)
-//    P4                                 -                        B-sub1(t+2) -> b, vmcnt   (A1,B0)
+//  phase of K-tile t (buffer b = t&1)   fragment reads             LDS-DMA issued           MFMA quadrant
+//    P1                                 B-sub0 (4), A-sub0 (2*TA)   A-sub1(t+1) -> b^1        (A0,B0)
+//    P2                                 B-sub1 (4)                  B-sub0(t+2) -> b          (A0,B1)
+//    P3                                 A-sub1 (2*TB)               A-sub0(t+2) -> b          (A1,B1)
+//    P4                                 -                           B-sub1(t+2) -> b, vmcnt   (A1,B0)
 //  RAW: a K-tile's data is waited for (counted vmcnt by each issuing wave) before P4's first barrier
 //  of the previous K-tile and first read in P1, i.e. after two further barriers - one more than the
 //  group stagger.  WAR: B-sub0 is re-staged one phase after its reads, which P1 retires with
-//  lgkmcnt(8) before its first barrier (reads issue B first); every other region two phases after.
+//  lgkmcnt(2*TA) before its first barrier (reads issue B first); every other region two phases after.
+//
+// Tail balancing: a launch may carry two kinds of tile.  Blocks [0, main_blocks) cover rows
+// [0, tail_row0) with the main tile, the rest cover [tail_row0, M) with 128x256 tiles; the hardware
+// hands out workgroups in block order, so the small tiles fill the last, partial round of the big
+// ones (612 big tiles on 256 CUs are 3 rounds; 504 big + 204 half-size tiles finish in about 2.65).
 //
 // Reference arithmetic replaced: the same nn.Linear calls as gemm_f16.hip ([tf] modeling_dinov3_vit.py
 // :307-309, :331, :356-357).
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <type_traits>
+#include <vector>
 #include "gemm_epilogue.h"
 
 namespace {
 
 constexpr int BK = 64;
+constexpr int BN = 256;
+
+struct PPGrid {               // block -> tile map of one launch
+    int main_blocks;          // blocks [0, main_blocks): main tiles over rows [0, tail_row0)
+    int tail_row0;            // first row of the tail segment (== M rounded up when there is none)
+};
 
 __device__ __forceinline__ f16x8 read_frag8(const char* lds_tile, int off) {
     return *reinterpret_cast<const f16x8*>(lds_tile + off);
 }
 
-template <int EPI, int TMH>
-__global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WROWS = 32 * TMH;                  // rows of C per wave
-    constexpr int BM = 2 * WROWS, BN = 256;
+template <int EPI, int TA, int TB>
+__device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0, char* smem) {
+    constexpr int TM = TA + TB;                      // 16-row MFMA tiles per wave
+    constexpr int WROWS = 16 * TM;                   // rows of C per wave
+    constexpr int BM = 2 * WROWS;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_PIECES = 4 * TMH;                // 8-row pieces per A sub-tile (both wave rows)
+    constexpr int TMAX = TA > TB ? TA : TB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-
-    const int tiles_n = p.N / BN;
-    const int bid = gemm_xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int row0 = tm * BM, col0 = tn * BN;
     const int nk = p.K / BK;                          // even, >= 2 (checked by the launcher)
 
     // ---- LDS-DMA source offsets: two 8-row pieces per wave and sub-tile --------------------------
-    // A-sub h = rows {wr' * WROWS + h * 16*TMH + [0, 16*TMH)}, wr' = 0,1;  B-sub h = rows with bit 5 == h.
-    // piece q of a sub-tile (q = wave, wave + 8); for TMH = 3 there are 12 A pieces: q is clamped, the
-    // duplicates rewrite identical bytes (keeps the per-wave DMA count, and so the vmcnt immediates, uniform)
+    // A-sub0 = rows {wr' * WROWS + [0, 16 TA)}, A-sub1 = rows {wr' * WROWS + 16 TA + [0, 16 TB)}, wr' = 0,1;
+    // B-sub h = rows with bit 5 == h.  Piece q of a sub-tile (q = wave, wave + 8); a sub-tile with fewer
+    // than 16 pieces clamps q: the duplicates rewrite identical bytes (keeps the per-wave DMA count, and
+    // so the vmcnt immediates, uniform)
     const int lrow = lane >> 3;
     int a_lds[2][2], b_lds[2][2];
     unsigned a_src[2][2], b_src[2][2];
@@ -65,9 +78,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            const int T = h ? TB : TA;
             int q = wave + 8 * s;
-            q = q < A_PIECES ? q : A_PIECES - 1;
-            const int ar = (q / (2 * TMH)) * WROWS + h * (16 * TMH) + (q % (2 * TMH)) * 8;   // first row of the piece
+            q = q < 4 * T ? q : 4 * T - 1;
+            const int ar = (q / (2 * T)) * WROWS + h * (16 * TA) + (q % (2 * T)) * 8;   // first row of the piece
             a_lds[h][s] = ar * 128;
             const int r = ar + lrow;
             int grow = row0 + r;
@@ -104,9 +118,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
         b_off[kk] = A_BYTES + (wc * 64 + frow) * 128 + sw;
     }
 
-    f32x4 acc[2 * TMH][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 2 * TMH; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
     if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
 
-    f16x8 a[TMH][2], b0[2][2], b1[2][2];
+    f16x8 a[TMAX][2], b0[2][2], b1[2][2];
 
 #define CBAS_SEG_BARRIER()                      \
     do {                                        \
@@ -130,25 +144,29 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
 
-    auto mfma_quadrant = [&](int ha, f16x8 (&bf)[2][2], int hb) {
+    auto mfma_quadrant = [&](auto ha_c, f16x8 (&bf)[2][2], int hb) {
+        constexpr int ha = decltype(ha_c)::value;
+        constexpr int T = ha ? TB : TA, I0 = ha ? TA : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < TMH; ++i)
+            for (int i = 0; i < T; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[ha * TMH + i][hb * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], a[i][kk], acc[ha * TMH + i][hb * 2 + j], 0, 0, 0);
+                    acc[I0 + i][hb * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], a[i][kk], acc[I0 + i][hb * 2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto read_a = [&](const char* buf, int h) {
+    auto read_a = [&](const char* buf, auto h_c) {
+        constexpr int h = decltype(h_c)::value;
+        constexpr int T = h ? TB : TA, I0 = h ? TA : 0;
 #pragma unroll
-        for (int i = 0; i < TMH; ++i)
+        for (int i = 0; i < T; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) a[i][kk] = read_frag8(buf, a_off[kk] + (h * TMH + i) * 2048);
+            for (int kk = 0; kk < 2; ++kk) a[i][kk] = read_frag8(buf, a_off[kk] + (I0 + i) * 2048);
     };
     auto read_b = [&](const char* buf, int h, f16x8 (&bf)[2][2]) {
 #pragma unroll
@@ -156,29 +174,34 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) bf[j][kk] = read_frag8(buf, b_off[kk] + (h * 2 + j) * 2048);
     };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
 
     auto ktile = [&](int b, int t) {
         const char* buf = smem + b * BUF_BYTES;
         // P1
         read_b(buf, 0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(buf, 0);
+        read_a(buf, H0{});
         if (t + 1 < nk) stage(b ^ 1, t + 1, 3);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 4 B-sub0 reads (issued first) are retired
+        // the 4 B-sub0 reads (issued first) are retired: 2*TA A reads may still be in flight
+        if (TA == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if (TA == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         CBAS_SEG_BARRIER();
-        mfma_quadrant(0, b0, 0);
+        mfma_quadrant(H0{}, b0, 0);
         CBAS_SEG_BARRIER();
         // P2
         read_b(buf, 1, b1);
         if (t + 2 < nk) stage(b, t + 2, 0);
         CBAS_SEG_BARRIER();
-        mfma_quadrant(0, b1, 1);
+        mfma_quadrant(H0{}, b1, 1);
         CBAS_SEG_BARRIER();
         // P3
-        read_a(buf, 1);
+        read_a(buf, H1{});
         if (t + 2 < nk) stage(b, t + 2, 1);
         CBAS_SEG_BARRIER();
-        mfma_quadrant(1, b1, 1);
+        mfma_quadrant(H1{}, b1, 1);
         CBAS_SEG_BARRIER();
         // P4
         if (t + 2 < nk) {
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         CBAS_SEG_BARRIER();
-        mfma_quadrant(1, b0, 0);
+        mfma_quadrant(H1{}, b0, 0);
         CBAS_SEG_BARRIER();
     };
 
@@ -200,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
 #undef CBAS_SEG_BARRIER
 
     if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
-    gemm_epilogue_tile<EPI, 2 * TMH>(p, row0 + wr * WROWS, col0 + wc * 64, lane, acc, smem + wave * 8192);
+    gemm_epilogue_tile<EPI, TM>(p, row0 + wr * WROWS, col0 + wc * 64, lane, acc, smem + wave * 8192);
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
@@ -208,28 +231,117 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p) {
     }
 }
 
-template <int EPI, int TMH>
-int launch_8ph(const GemmParams& p, hipStream_t stream) {
-    constexpr int BM = 64 * TMH, BN = 256;
+// TAIL = 1: blocks past g.main_blocks run 128x256 tiles over rows [g.tail_row0, M)
+template <int EPI, int TA, int TB, int TAIL>
+__global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGrid g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = p.N / BN;
+    if (!TAIL || (int)blockIdx.x < g.main_blocks) {
+        const int bid = gemm_xcd_remap(blockIdx.x, TAIL ? g.main_blocks : (int)gridDim.x);
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        pp_tile<EPI, TA, TB>(p, tm * 32 * (TA + TB), tn * BN, smem);
+    } else {
+        const int bid = gemm_xcd_remap(blockIdx.x - g.main_blocks, gridDim.x - g.main_blocks);
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        pp_tile<EPI, 2, 2>(p, g.tail_row0 + tm * 128, tn * BN, smem);
+    }
+}
+
+template <int EPI, int TA, int TB, int TAIL>
+int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
+    constexpr int BM = 32 * (TA + TB);
     constexpr int lds = 2 * (BM * 128 + BN * 128);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static_assert(lds >= 8 * 8192, "epilogue scratch");
+    static_assert(lds >= 8 * 8192 && 2 * (128 * 128 + BN * 128) >= 8 * 8192, "epilogue scratch");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_8ph_kernel<EPI, TMH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_8ph_kernel<EPI, TA, TB, TAIL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TMH>), dim3(grid), dim3(512), lds, stream, p);
+    const int tiles_n = p.N / BN;
+    PPGrid g;
+    int grid;
+    if (TAIL) {
+        g.main_blocks = main_panels * tiles_n;
+        g.tail_row0 = main_panels * BM;
+        if (g.tail_row0 >= p.M) return -1;
+        grid = g.main_blocks + ((p.M - g.tail_row0 + 127) / 128) * tiles_n;
+    } else {
+        grid = ((p.M + BM - 1) / BM) * tiles_n;
+        g.main_blocks = grid;
+        g.tail_row0 = p.M;
+    }
+    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL>), dim3(grid), dim3(512), lds, stream, p, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Makespan of a launch on `slots` CUs, in units of one 256x256 tile: tiles are handed out in block
+// order to whichever CU frees up first.  Relative tile costs measured with scripts/gemm_stamps.py
+// (the smaller tiles are bound by the ~30 B/cycle/CU L2->LDS rate, not by the MFMA pipe).
+double pp_tile_cost(int bm) { return bm == 256 ? 1.0 : bm == 192 ? 0.86 : bm == 160 ? 0.83 : 0.66; }
+
+double pp_makespan(int n_main, double c_main, int n_tail, double c_tail, int slots) {
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int i = 0; i < slots; ++i) free_at.push(0.0);
+    double end = 0.0;
+    auto run = [&](int n, double c) {
+        for (int i = 0; i < n; ++i) {
+            const double t = free_at.top() + c;
+            free_at.pop();
+            free_at.push(t);
+            if (t > end) end = t;
+        }
+    };
+    run(n_main, c_main);
+    run(n_tail, c_tail);
+    return end;
+}
+
+struct PPPlan { int bm; int main_panels; };
+
+// plan for an (M, N) problem on this device; computed once per shape
+PPPlan pp_plan(int M, int N) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, PPPlan> cache;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({M, N});
+    if (it != cache.end()) return it->second;
+    const int tiles_n = N / BN;
+    PPPlan best{256, 0};
+    double best_t = 1e30;
+    for (int bm : {256, 192, 160}) {
+        const int n = ((M + bm - 1) / bm) * tiles_n;
+        const double t = pp_makespan(n, pp_tile_cost(bm), 0, 0.0, cus);
+        if (t < best_t - 1e-9) { best = {bm, 0}; best_t = t; }
+    }
+    for (int mp = 1; mp * 256 < M; ++mp) {
+        const int n_main = mp * tiles_n, n_tail = ((M - mp * 256 + 127) / 128) * tiles_n;
+        const double t = pp_makespan(n_main, 1.0, n_tail, pp_tile_cost(128), cus);
+        if (t < best_t - 0.02) { best = {256, mp}; best_t = t; }      // prefer a uniform grid on near-ties
+    }
+    cache[{M, N}] = best;
+    return best;
 }
 
 template <int EPI>
 int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
-    if (tile == GEMM_TILE_PP_192x256) return launch_8ph<EPI, 3>(p, stream);
-    return launch_8ph<EPI, 4>(p, stream);
+    if (tile == GEMM_TILE_PP_192x256) return launch_8ph<EPI, 3, 3, 0>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_160x256) return launch_8ph<EPI, 3, 2, 0>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_128x256) return launch_8ph<EPI, 2, 2, 0>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_256x256) return launch_8ph<EPI, 4, 4, 0>(p, 0, stream);
+    // GEMM_TILE_PP_AUTO: uniform 256 / 192 / 160-row tiles, or 256-row tiles with a 128-row tail
+    const PPPlan plan = pp_plan(p.M, p.N);
+    if (plan.main_panels) return launch_8ph<EPI, 4, 4, 1>(p, plan.main_panels, stream);
+    if (plan.bm == 192) return launch_8ph<EPI, 3, 3, 0>(p, 0, stream);
+    if (plan.bm == 160) return launch_8ph<EPI, 3, 2, 0>(p, 0, stream);
+    return launch_8ph<EPI, 4, 4, 0>(p, 0, stream);
 }
 
 }  // namespace

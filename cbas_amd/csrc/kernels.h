@@ -19,7 +19,8 @@ enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2
                 GEMM_TILE_RING_256x256_W16 = 5, GEMM_TILE_RING_256x256_W8 = 6,
                 GEMM_TILE_192x256 = 7,
                 GEMM_TILE_PP_256x256 = 13,      // gemm_f16_8ph.hip: 8 waves, ping-pong phases, counted vmcnt
-                GEMM_TILE_PP_192x256 = 14 };
+                GEMM_TILE_PP_192x256 = 14, GEMM_TILE_PP_160x256 = 15, GEMM_TILE_PP_128x256 = 16,
+                GEMM_TILE_PP_AUTO = 17 };       // planner: uniform tile height, or 256-row tiles + 128-row tail
 
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)
