@@ -183,7 +183,7 @@ def main() -> None:
         g_n = sum(prof[k]["launches"] for k in gemm)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_f16_kernel (all epilogues: patch/qkv/o_proj/up/down)",
+            "bound": "mfma", "kernel": "gemm_f16_8ph_kernel (all epilogues: patch/qkv/o_proj/up/down)",
             "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
             "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "launches": g_n,

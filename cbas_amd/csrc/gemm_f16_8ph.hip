@@ -337,7 +337,9 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
     if (tile == GEMM_TILE_PP_128x256) return launch_8ph<EPI, 2, 2, 0>(p, 0, stream);
     if (tile == GEMM_TILE_PP_256x256) return launch_8ph<EPI, 4, 4, 0>(p, 0, stream);
     // GEMM_TILE_PP_AUTO: uniform 256 / 192 / 160-row tiles, or 256-row tiles with a 128-row tail
-    const PPPlan plan = pp_plan(p.M, p.N);
+    PPPlan plan = pp_plan(p.M, p.N);
+    static const int mp_env = [] { const char* e = getenv("CBAS_PP_MAIN_PANELS"); return e ? atoi(e) : -1; }();
+    if (mp_env >= 0 && mp_env * 256 < p.M) plan = {256, mp_env};                 // experiments only
     if (plan.main_panels) return launch_8ph<EPI, 4, 4, 1>(p, plan.main_panels, stream);
     if (plan.bm == 192) return launch_8ph<EPI, 3, 3, 0>(p, 0, stream);
     if (plan.bm == 160) return launch_8ph<EPI, 3, 2, 0>(p, 0, stream);
