@@ -71,3 +71,14 @@ def cls_walk(seed: int, n: int, dim: int) -> np.ndarray:
         acc = 0.97 * acc + steps[i]
         walk[i] = acc
     return (base + walk + jitter).astype(np.float16)
+
+
+def train_windows(seed: int, n: int, dim: int, n_classes: int, seq_len: int = 31):
+    """Labelled training windows (n, seq_len, dim) float32 + labels (n,) int64: windows of a CLS-like
+    walk with a class-dependent offset, so a head can learn them (training goldens, tests, bench)."""
+    rng = np.random.default_rng(seed)
+    seq = cls_walk(seed, n + seq_len - 1, dim).astype(np.float32)
+    x = np.stack([seq[i:i + seq_len] for i in range(n)])
+    y = rng.integers(0, n_classes, n).astype(np.int64)
+    proto = synth_normal(seed, "train_proto", (n_classes, dim), 0.5).astype(np.float32)
+    return (x + proto[y][:, None, :]).astype(np.float32), y

@@ -263,6 +263,95 @@ def g_head(out):
         print("head", tag, logits.shape, latent.shape)
 
 
+class _MaskDropout(torch.nn.Module):
+    """Stand-in for an nn.Dropout of the reference module: same arithmetic (x * keep / (1-p)) with the
+    keep-mask taken from the shared counter-based hash instead of torch's global RNG."""
+
+    def __init__(self, p, stream, bank):
+        super().__init__()
+        self.p, self.stream, self.bank = p, stream, bank
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        keep = self.bank["masks"][self.stream]
+        return x * keep.to(x.dtype) / (1.0 - self.p)
+
+
+TRAIN_SAMPLE_STRIDE = 13
+
+
+def _pack(res, key, a):
+    """Keep the fixtures small: tensors over 4096 elements are stored as every 13th element (flat
+    order) plus their L2 norm and sum; small tensors in full."""
+    a = np.asarray(a, np.float32)
+    if a.size > 4096:
+        res[key + "#sample"] = a.reshape(-1)[::TRAIN_SAMPLE_STRIDE].copy()
+        res[key + "#norm"] = np.float64(np.linalg.norm(a.astype(np.float64)))
+        res[key + "#sum"] = np.float64(a.astype(np.float64).sum())
+    else:
+        res[key] = a.copy()
+
+
+def train_problem(hcfg: C.HeadConfig, B: int, seed: int):
+    """Synthetic labelled windows: a class-dependent offset on top of a CLS-like walk."""
+    return synth.train_windows(seed, B, hcfg.in_features, hcfg.out_features, hcfg.seq_len)
+
+
+def g_head_train(out):
+    """Reference ClassifierLSTMDeltas in train() mode + the loss / optimiser lines of
+    train_lstm_model (cbas.py:1305-1311, :1331-1348) on fixed batches, dropout masks injected."""
+    _, classifier_head = import_reference()
+    from oracle import head_train_oracle as HT
+    torch.set_grad_enabled(True)                 # the rest of this script runs under no-grad
+    for tag, h, nl, B, wd, ls, use_cw in (("h64", 64, 1, 48, 0.0, 0.0, False), ("h64_l2", 64, 2, 32, 1e-2, 0.1, True),
+                                          ("h128", 128, 1, 32, 0.0, 0.05, True)):
+        hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl)
+        hw = W.synth_head_weights(hcfg, HEAD_SEED)
+        m = classifier_head.ClassifierLSTMDeltas(in_features=768, out_features=9, seq_len=31, lstm_hidden_size=h,
+                                                 lstm_layers=nl)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in hw.items()}, strict=True)
+        bank = {"masks": None}
+        m.cls_bottleneck[2] = _MaskDropout(0.1, "cls", bank)
+        m.delta_bottleneck[2] = _MaskDropout(0.1, "delta", bank)
+        m.acc_bottleneck[2] = _MaskDropout(0.1, "acc", bank)
+        m.lin0[2] = _MaskDropout(0.15, "lin0", bank)
+        m.train()
+        lr, seed, n_steps = 1e-3, 77, 3
+        optimizer = torch.optim.Adam([                                               # cbas.py:1305-1308
+            {"params": [p for name, p in m.named_parameters() if name != "gate"]},
+            {"params": m.gate, "weight_decay": 1e-3}], lr=lr, weight_decay=wd)
+        cw = np.linspace(0.5, 1.5, 9).astype(np.float32) if use_cw else None
+        criterion = torch.nn.CrossEntropyLoss(weight=None if cw is None else torch.from_numpy(cw), label_smoothing=ls)
+        x, y = train_problem(hcfg, B, 5)
+        res = {"lr": lr, "seed": seed, "weight_decay": wd, "label_smoothing": ls, "B": B}
+        if cw is not None:
+            res["class_weights"] = cw
+        for s in range(n_steps):
+            bank["masks"] = HT.make_masks(seed, s, B, 31, 128, 256)
+            optimizer.zero_grad()
+            final_logits, rawm = m(torch.from_numpy(x))
+            inv_loss = criterion(final_logits, torch.from_numpy(y))
+            rawm_centered = rawm - rawm.mean(dim=0)                                  # cbas.py:1338-1343
+            covm = (rawm_centered.T @ rawm_centered) / (rawm_centered.shape[0] - 1)
+            n_ = covm.shape[0]
+            covm_loss = torch.sum(torch.pow(covm.flatten()[:-1].view(n_ - 1, n_ + 1)[:, 1:].flatten(), 2))
+            loss = inv_loss + covm_loss
+            loss.backward()
+            if s == 0:
+                res["loss0"], res["ce0"], res["cov0"] = float(loss), float(inv_loss), float(covm_loss)
+                res["logits0"], res["latent0"] = final_logits.detach().numpy(), rawm.detach().numpy()
+                for name, p in m.named_parameters():
+                    _pack(res, "grad0/" + name, p.grad.detach().numpy())
+            res[f"loss{s}"] = float(loss)
+            optimizer.step()
+        for name, p in m.named_parameters():
+            _pack(res, "final/" + name, p.detach().numpy())
+        np.savez_compressed(os.path.join(out, f"head_train_{tag}.npz"), **res)
+        print("head_train", tag, [res[f"loss{s}"] for s in range(n_steps)])
+    torch.set_grad_enabled(False)
+
+
 def g_infer(out):
     """cbas.infer_file end to end on synthetic _cls.h5 contents: edge padding, halo chunking,
     temperature clamp, and the CSV text pandas writes."""
@@ -399,7 +488,7 @@ def g_dinov2(out):
 
 
 ALL = {"dinov2": g_dinov2, "tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
-       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "infer": g_infer, "e2e": g_e2e,
+       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e,
        "encode_file": g_encode_file}
 
 if __name__ == "__main__":
