@@ -31,6 +31,11 @@ class HeadConfigC(C.Structure):
                 ("center_window_size", c_int32), ("ema_alpha", c_float), ("lstm_layers", c_int32)]
 
 
+class TrainConfigC(C.Structure):
+    _fields_ = [("lr", c_float), ("weight_decay", c_float), ("label_smoothing", c_float), ("max_batch", c_int32),
+                ("seed", C.c_uint64), ("dropout", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/cbas_mi355x.h declares
 SIGNATURES = {
     "cbas_enc_weights_count": (c_int64, [C.POINTER(EncConfig)]),
@@ -56,6 +61,12 @@ SIGNATURES = {
     "cbas_head_infer_f16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "cbas_head_infer_f16_range": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_void_p,
                                           c_void_p]),
+    "cbas_head_train_create": (c_int, [C.POINTER(HeadConfigC), C.POINTER(TrainConfigC), c_void_p, c_int64, c_void_p, c_int,
+                                       C.POINTER(c_void_p)]),
+    "cbas_head_train_destroy": (None, [c_void_p]),
+    "cbas_head_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "cbas_head_train_read": (c_int, [c_void_p, c_int32, c_void_p, c_int64]),
+    "cbas_head_train_last_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_int32]),
     "cbas_last_error": (C.c_char_p, []),
     "cbas_abi_version": (c_int, []),
     "cbas_device_info": (c_int, [c_int, C.c_char_p, c_int, C.POINTER(c_int32), C.POINTER(c_int64)]),

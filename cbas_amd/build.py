@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libcbas_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["gemm_f16.hip", "gemm_f16_ring.hip", "gemm_f16_8ph.hip", "gemm_f32.hip", "vit_kernels.hip", "head_kernels.hip", "api_enc.hip", "api_head.hip"]
+SOURCES = ["gemm_f16.hip", "gemm_f16_ring.hip", "gemm_f16_8ph.hip", "gemm_f32.hip", "vit_kernels.hip", "head_kernels.hip", "head_train_kernels.hip",
+           "api_enc.hip", "api_head.hip", "api_head_train.hip"]
 ARCH = "gfx950"
 
 
@@ -46,9 +47,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         srcp = os.path.join(CSRC, src)
+        headers = [os.path.join(CSRC, hname) for hname in os.listdir(CSRC) if hname.endswith(".h")]
+        headers.append(os.path.join(HERE, "..", "include", "cbas_mi355x.h"))
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
-                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, hname))
-                        for hname in os.listdir(CSRC) if hname.endswith(".h"))):
+                and all(os.path.getmtime(obj) > os.path.getmtime(hp) for hp in headers)):
             continue
         cmd = [hipcc, *common, "-c", srcp, "-o", obj]
         if verbose:

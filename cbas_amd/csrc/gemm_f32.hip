@@ -58,6 +58,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Gemm32Params p) {
     const int64_t row0 = (int64_t)tm * BM;
     const int col0 = tn * BN;
     const int nk = p.K / BKF;
+    const int64_t ldw = p.ldw ? p.ldw : p.K;
+    const int64_t koff = (int64_t)blockIdx.z * p.K;            // split-K: this block's k range starts here
+    const float* __restrict__ Ap = p.A + koff;
+    const float* __restrict__ Wp = p.W + koff;
+    float* __restrict__ outp = p.out + (int64_t)blockIdx.z * p.split_stride;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Gemm32Params p) {
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * BUF_BYTES;
-        stage_tile32(p.A, p.lda, row0, p.M - 1, kt * BKF, base, wave, lane);
-        stage_tile32(p.W, p.K, col0, p.N_alloc - 1, kt * BKF, base + TILE_BYTES, wave, lane);
+        stage_tile32(Ap, p.lda, row0, p.M - 1, kt * BKF, base, wave, lane);
+        stage_tile32(Wp, ldw, col0, p.N_alloc - 1, kt * BKF, base + TILE_BYTES, wave, lane);
     };
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Gemm32Params p) {
             f32x4 v = acc[i][j];
             if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
             if (GELU) v = f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
-            *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
+            *reinterpret_cast<f32x4*>(outp + m * p.ldo + n) = v;
         }
     }
 }
@@ -128,13 +133,31 @@ int launch32(const Gemm32Params& p, hipStream_t stream) {
     }
     const int64_t grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     if (grid <= 0 || grid > 0x7fffffff) return -1;
-    hipLaunchKernelGGL((gemm_f32_kernel<GELU>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+    const unsigned gz = p.splits > 1 ? (unsigned)p.splits : 1u;
+    hipLaunchKernelGGL((gemm_f32_kernel<GELU>), dim3((unsigned)grid, 1, gz), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 }  // namespace
 
+namespace {
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t stride, int64_t n,
+                                     float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = partial[i];
+    for (int z = 1; z < splits; ++z) s += partial[(int64_t)z * stride + i];
+    dst[i] = s;
+}
+}  // namespace
+
+int launch_splitk_reduce(const float* partial, int splits, int64_t stride, int64_t n, float* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, splits, stride, n, dst);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_gemm_f32(const Gemm32Params& p, int gelu, hipStream_t stream) {
-    if (p.M <= 0 || p.N <= 0 || p.N % 4 || p.K % BKF || p.N_alloc < p.N || p.lda % 4 || p.ldo % 4) return -1;
+    if (p.M <= 0 || p.N <= 0 || p.N % 4 || p.K % BKF || p.N_alloc < p.N || p.lda % 4 || p.ldo % 4 || p.ldw % 4) return -1;
+    if (p.splits > 1 && (p.bias || gelu || p.split_stride % 4)) return -1;
     return gelu ? launch32<1>(p, stream) : launch32<0>(p, stream);
 }

@@ -1,0 +1,684 @@
+// Training kernels of the classifier head (one optimisation step of train_lstm_model,
+// backend/cbas.py:1326-1348, on ClassifierLSTMDeltas in train() mode, backend/classifier_head.py:150-172).
+// All arithmetic is fp32.  The GEMM-shaped parts (projections, W_ih, all weight gradients) go through
+// the exact-fp32 MFMA GEMM of gemm_f32.hip with explicit transposes; this file holds the rest:
+//
+//   forward                                   backward
+//   train_expand_fwd   (EMA/delta/accel as   train_expand_bwd   (LayerNorm, dropout, GELU', the
+//     T x T matrices on the projected rows,     transposed temporal matrices, lin1 branch)
+//     bias, GELU, dropout, LayerNorm, lin1)
+//   gelu_dropout_fwd   (lin0 activation)      gelu_dropout_bwd
+//   lstm_train_fwd     (saves gates, c, h)    lstm_train_bwd     (BPTT -> d(pre-activations), h_{t-1})
+//   pool_train_fwd     (attention pooling,    pool_train_bwd
+//     lin2, gate lerp)
+//   ce_terms / ce_grad (weighted, label-smoothed cross entropy), cov_offdiag (covariance penalty)
+//   colsum (deterministic two-stage column sums), transpose_pad, adam_step
+//
+// Dropout keep-masks are a counter-based hash of (seed, step, stream, element index) so that the CPU
+// oracle draws the same masks (oracle/head_train_oracle.py: dropout_keep).
+#include "kernels.h"
+
+namespace {
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// keep <=> top 24 bits of the element hash >= thr  (thr = floor(p * 2^24); thr = 0 keeps everything)
+__device__ __forceinline__ float drop_scale(unsigned long long key, unsigned long long idx, unsigned thr, float scale) {
+    return (unsigned)(mix64(key + idx) >> 40) >= thr ? scale : 0.f;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// d/dx gelu_erf(x) = Phi(x) + x phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red, int nwaves) {   // all threads get the sum
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nwaves; ++i) s += red[i];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void transpose_pad_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld,
+                                     float* __restrict__ dst, int64_t rows_pad) {
+    __shared__ float tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t r = r0 + i;
+        const int c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const int64_t r = r0 + tx;
+        if (c < cols && r < rows_pad) dst[(int64_t)c * rows_pad + r] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// expand forward: one workgroup per window, one thread per (stream k, channel c) of the 3*Bn outputs.
+// ---------------------------------------------------------------------------------------------
+struct ExpandArgs {
+    const float* proj;       // [w][T][NPROJ]
+    const float* tmat;       // [3][T][T]: row t of stream k = weights over t' (EMA, delta o EMA, accel o EMA)
+    const float* lin_vec;    // [T]: mean over the centre window of the EMA rows
+    const float* b_bott;     // [3 Bn]
+    const float* ln_w;       // [3 Bn]
+    const float* ln_b;       // [3 Bn]
+    const float* b_lin1;     // [C]
+    int T, Bn, NPROJ, C;
+    unsigned long long key[3];
+    unsigned thr; float scale;
+};
+
+__global__ __launch_bounds__(768) void train_expand_fwd_kernel(ExpandArgs a, float* __restrict__ Y, float* __restrict__ aug,
+                                                               float* __restrict__ lin_logits) {
+    extern __shared__ float sm[];
+    const int T = a.T, Bn = a.Bn, F = 3 * Bn, NP = a.NPROJ;
+    float* P = sm;                       // [T][NP]
+    float* TM = P + T * NP;              // [3][T][T]
+    float* U = TM + 3 * T * T;           // [T][F]
+    const int64_t w = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < T * NP; i += blockDim.x) P[i] = a.proj[w * T * NP + i];
+    for (int i = tid; i < 3 * T * T; i += blockDim.x) TM[i] = a.tmat[i];
+    __syncthreads();
+    if (tid < F) {
+        const int k = tid / Bn;
+        const float bias = a.b_bott[tid];
+        const float* tm = TM + k * T * T;
+        for (int t = 0; t < T; ++t) {
+            float y = 0.f;
+            for (int s = 0; s < T; ++s) y = fmaf(tm[t * T + s], P[s * NP + tid], y);
+            y += bias;
+            const int64_t e = (w * T + t) * F + tid;
+            Y[e] = y;
+            // dropout index = row-major index inside the stream's own (B, T, Bn) tensor
+            const unsigned long long di = (unsigned long long)((w * T + t) * Bn + (tid - k * Bn));
+            U[t * F + tid] = gelu_erf(y) * drop_scale(a.key[k], di, a.thr, a.scale);
+        }
+    }
+    if (tid < a.C) {                     // linear branch: mean over the centre window of lin1(EMA(x))
+        float v = 0.f;
+        for (int s = 0; s < T; ++s) v = fmaf(a.lin_vec[s], P[s * NP + F + tid], v);
+        lin_logits[w * a.C + tid] = v + a.b_lin1[tid];
+    }
+    __syncthreads();
+    // LayerNorm of each (t, k) row of Bn values: one wave per row, two-pass statistics
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int row = wave; row < 3 * T; row += nw) {
+        const int t = row / 3, k = row - t * 3;
+        const float* u = U + t * F + k * Bn;
+        float s = 0.f;
+        for (int c = lane; c < Bn; c += 64) s += u[c];
+        const float mean = wave_sum(s) / (float)Bn;
+        float q = 0.f;
+        for (int c = lane; c < Bn; c += 64) { const float d = u[c] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)Bn + 1e-5f);
+        for (int c = lane; c < Bn; c += 64)
+            aug[(w * T + t) * F + k * Bn + c] = (u[c] - mean) * rstd * a.ln_w[k * Bn + c] + a.ln_b[k * Bn + c];
+    }
+}
+
+// expand backward.  part[w] = [ d b_bott (F) | d ln_w (F) | d ln_b (F) ] per-window partial sums.
+__global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, const float* __restrict__ Y,
+                                                               const float* __restrict__ daug, const float* __restrict__ dlin,
+                                                               float* __restrict__ dproj, float* __restrict__ part) {
+    extern __shared__ float sm[];
+    const int T = a.T, Bn = a.Bn, F = 3 * Bn, NP = a.NPROJ;
+    float* TM = sm;                      // [3][T][T]
+    float* U = TM + 3 * T * T;           // [T][F]   dropped GELU outputs (LayerNorm inputs)
+    float* ST = U + T * F;               // [3T][4]  mean, rstd, sum(dxhat)/Bn, sum(dxhat*xhat)/Bn
+    const int64_t w = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * T * T; i += blockDim.x) TM[i] = a.tmat[i];
+    const int k = tid < F ? tid / Bn : 0;
+    if (tid < F) {
+        for (int t = 0; t < T; ++t) {
+            const float y = Y[(w * T + t) * F + tid];
+            const unsigned long long di = (unsigned long long)((w * T + t) * Bn + (tid - k * Bn));
+            U[t * F + tid] = gelu_erf(y) * drop_scale(a.key[k], di, a.thr, a.scale);
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int row = wave; row < 3 * T; row += nw) {
+        const int t = row / 3, kk = row - t * 3;
+        const float* u = U + t * F + kk * Bn;
+        float s = 0.f;
+        for (int c = lane; c < Bn; c += 64) s += u[c];
+        const float mean = wave_sum(s) / (float)Bn;
+        float q = 0.f;
+        for (int c = lane; c < Bn; c += 64) { const float d = u[c] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)Bn + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < Bn; c += 64) {
+            const float dxh = daug[(w * T + t) * F + kk * Bn + c] * a.ln_w[kk * Bn + c];
+            s1 += dxh;
+            s2 += dxh * (u[c] - mean) * rstd;
+        }
+        s1 = wave_sum(s1) / (float)Bn;
+        s2 = wave_sum(s2) / (float)Bn;
+        if (lane == 0) { ST[row * 4 + 0] = mean; ST[row * 4 + 1] = rstd; ST[row * 4 + 2] = s1; ST[row * 4 + 3] = s2; }
+    }
+    __syncthreads();
+    if (tid < F) {
+        const float gamma = a.ln_w[tid];
+        float dgam = 0.f, dbet = 0.f, dbias = 0.f;
+        // dY[t] overwrites this thread's column of U (only this thread touches it from here on)
+        for (int t = 0; t < T; ++t) {
+            const float* st = ST + (t * 3 + k) * 4;
+            const float xhat = (U[t * F + tid] - st[0]) * st[1];
+            const float dy = daug[(w * T + t) * F + tid];
+            dgam += dy * xhat;
+            dbet += dy;
+            const float du = st[1] * (dy * gamma - st[2] - xhat * st[3]);
+            const float y = Y[(w * T + t) * F + tid];
+            const unsigned long long di = (unsigned long long)((w * T + t) * Bn + (tid - k * Bn));
+            const float dyv = du * drop_scale(a.key[k], di, a.thr, a.scale) * gelu_erf_grad(y);
+            dbias += dyv;
+            U[t * F + tid] = dyv;
+        }
+        const float* tm = TM + k * T * T;
+        for (int s = 0; s < T; ++s) {                   // transposed temporal matrix
+            float v = 0.f;
+            for (int t = 0; t < T; ++t) v = fmaf(tm[t * T + s], U[t * F + tid], v);
+            dproj[(w * T + s) * NP + tid] = v;
+        }
+        part[w * 3 * F + tid] = dbias;
+        part[w * 3 * F + F + tid] = dgam;
+        part[w * 3 * F + 2 * F + tid] = dbet;
+    }
+    if (tid < NP - F) {                                 // lin1 columns and the zero padding columns
+        const int c = tid;
+        const float g = c < a.C ? dlin[w * a.C + c] : 0.f;
+        for (int s = 0; s < T; ++s) dproj[(w * T + s) * NP + F + c] = a.lin_vec[s] * g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void gelu_dropout_fwd_kernel(const float* __restrict__ Z, float* __restrict__ out, int64_t n,
+                                        unsigned long long key, unsigned thr, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gelu_erf(Z[i]) * drop_scale(key, (unsigned long long)i, thr, scale);
+}
+__global__ void gelu_dropout_bwd_kernel(const float* __restrict__ Z, float* __restrict__ d, int64_t n,
+                                        unsigned long long key, unsigned thr, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = d[i] * drop_scale(key, (unsigned long long)i, thr, scale) * gelu_erf_grad(Z[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM forward that keeps what BPTT needs.  grid (windows, 2 directions), 4h threads: thread r owns gate
+// row r = gate*h + unit with its W_hh row in registers.  gin/act: [w][t][dir*4h + r]; cst/hout: [w][t][dir*h + u].
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_train_fwd_kernel(const float* __restrict__ gin, const float* __restrict__ w_hh,
+                                                               int T, float* __restrict__ act, float* __restrict__ cst,
+                                                               float* __restrict__ hout) {
+    __shared__ float hprev[H];
+    __shared__ float gates[4 * H];
+    const int64_t w = blockIdx.x;
+    const int dir = blockIdx.y, r = threadIdx.x, gate = r / H;
+    float wrow[H];
+#pragma unroll
+    for (int u = 0; u < H; ++u) wrow[u] = w_hh[((size_t)dir * 4 * H + r) * H + u];
+    if (r < H) hprev[r] = 0.f;
+    float c = 0.f;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const int64_t row = w * T + t;
+        float pre = gin[row * 8 * H + dir * 4 * H + r];
+#pragma unroll
+        for (int u = 0; u < H; ++u) pre = fmaf(wrow[u], hprev[u], pre);
+        const float a = gate == 2 ? tanhf(pre) : sigmoidf_(pre);
+        act[row * 8 * H + dir * 4 * H + r] = a;
+        gates[r] = a;
+        __syncthreads();
+        if (r < H) {
+            c = gates[H + r] * c + gates[r] * gates[2 * H + r];
+            const float hn = gates[3 * H + r] * tanhf(c);
+            cst[row * 2 * H + dir * H + r] = c;
+            hout[row * 2 * H + dir * H + r] = hn;
+            hprev[r] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// BPTT.  Thread j = q*H + u holds the column segment W_hh[q*H + k][u], k < H, so that
+// dh_{prev}[u] = sum_q sum_k W_hh[q*H+k][u] * da[q*H+k] is four partial sums per unit.
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_train_bwd_kernel(const float* __restrict__ dhout, const float* __restrict__ act,
+                                                               const float* __restrict__ cst, const float* __restrict__ hout,
+                                                               const float* __restrict__ w_hh, int T,
+                                                               float* __restrict__ dgin, float* __restrict__ hprev_out) {
+    __shared__ float da[4 * H];
+    __shared__ float partial[4 * H];
+    const int64_t w = blockIdx.x;
+    const int dir = blockIdx.y, j = threadIdx.x, q = j / H, u = j - q * H;
+    float wcol[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) wcol[k] = w_hh[((size_t)dir * 4 * H + q * H + k) * H + u];
+    float dh_rec = 0.f, dc_rec = 0.f;
+    for (int step = T - 1; step >= 0; --step) {                 // reverse of the forward recursion order
+        const int t = dir ? T - 1 - step : step;
+        const int tp = dir ? t + 1 : t - 1;                      // the step that fed this one
+        const bool has_prev = step > 0;
+        const int64_t row = w * T + t;
+        if (j < H) {
+            const float* a = act + row * 8 * H + dir * 4 * H;
+            const float ig = a[j], fg = a[H + j], gg = a[2 * H + j], og = a[3 * H + j];
+            const float c = cst[row * 2 * H + dir * H + j];
+            const float cp = has_prev ? cst[(w * T + tp) * 2 * H + dir * H + j] : 0.f;
+            const float dh = dhout[row * 2 * H + dir * H + j] + dh_rec;
+            const float tc = tanhf(c);
+            const float dc = dc_rec + dh * og * (1.0f - tc * tc);
+            const float dai = dc * gg * ig * (1.0f - ig);
+            const float daf = dc * cp * fg * (1.0f - fg);
+            const float dag = dc * ig * (1.0f - gg * gg);
+            const float dao = dh * tc * og * (1.0f - og);
+            dc_rec = dc * fg;
+            da[j] = dai; da[H + j] = daf; da[2 * H + j] = dag; da[3 * H + j] = dao;
+            float* g = dgin + row * 8 * H + dir * 4 * H;
+            g[j] = dai; g[H + j] = daf; g[2 * H + j] = dag; g[3 * H + j] = dao;
+            hprev_out[row * 2 * H + dir * H + j] = has_prev ? hout[(w * T + tp) * 2 * H + dir * H + j] : 0.f;
+        }
+        __syncthreads();
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) p = fmaf(wcol[k], da[q * H + k], p);
+        partial[j] = p;
+        __syncthreads();
+        if (j < H) dh_rec = (partial[j] + partial[H + j]) + (partial[2 * H + j] + partial[3 * H + j]);
+        // da / partial are rewritten only after the next iteration's first barrier
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention pooling + lin2 + gate (classifier_head.py:131-148, :171).  One workgroup (2h threads) per window.
+// ---------------------------------------------------------------------------------------------
+struct PoolArgs {
+    const float* hout;        // [w][T][2h] last LSTM layer
+    const float* lin_logits;  // [w][C]
+    const float* w_att; const float* b_att;     // [2h], [1]
+    const float* att_temp;    // raw parameter
+    const float* w_lin2; const float* b_lin2;   // [C][2h], [C]
+    const float* gate;        // raw parameter
+    int T, H2, C, lo, hi;
+};
+
+__device__ __forceinline__ float softplus_temp(float raw) { return (raw > 20.f ? raw : log1pf(expf(raw))) + 1e-3f; }
+
+__global__ __launch_bounds__(256) void pool_train_fwd_kernel(PoolArgs a, float* __restrict__ attw, float* __restrict__ scores,
+                                                             float* __restrict__ latent, float* __restrict__ lstm_logits,
+                                                             float* __restrict__ final_logits) {
+    __shared__ float red[4];
+    __shared__ float sc[128];
+    __shared__ float lat[256];
+    const int64_t w = blockIdx.x;
+    const int u = threadIdx.x, nwv = blockDim.x >> 6, nc = a.hi - a.lo;
+    const float temp = softplus_temp(a.att_temp[0]);
+    const float wa = a.w_att[u];
+    for (int t = 0; t < nc; ++t) {
+        const float s = block_sum(a.hout[(w * a.T + a.lo + t) * a.H2 + u] * wa, red, nwv);
+        if (u == 0) sc[t] = (s + a.b_att[0]) / temp;
+    }
+    __syncthreads();
+    float mx = -3.4e38f;
+    for (int t = 0; t < nc; ++t) mx = fmaxf(mx, sc[t]);
+    float den = 0.f;
+    for (int t = 0; t < nc; ++t) den += expf(sc[t] - mx);
+    float l = 0.f;
+    for (int t = 0; t < nc; ++t) {
+        const float aw = expf(sc[t] - mx) / den;
+        l = fmaf(aw, a.hout[(w * a.T + a.lo + t) * a.H2 + u], l);
+        if (u == 0) { attw[w * nc + t] = aw; scores[w * nc + t] = sc[t]; }
+    }
+    latent[w * a.H2 + u] = l;
+    lat[u] = l;
+    __syncthreads();
+    if (u < a.C) {
+        float v = a.b_lin2[u];
+        for (int k = 0; k < a.H2; ++k) v = fmaf(lat[k], a.w_lin2[u * a.H2 + k], v);
+        lstm_logits[w * a.C + u] = v;
+        const float g = sigmoidf_(a.gate[0]);
+        const float ll = a.lin_logits[w * a.C + u];
+        final_logits[w * a.C + u] = ll + g * (v - ll);
+    }
+}
+
+// part[w] = [ d w_att (2h) | d b_att,0,0,0 | d gate,0,0,0 | d att_temp,0,0,0 ]  (the layout order of those parameters)
+__global__ __launch_bounds__(256) void pool_train_bwd_kernel(PoolArgs a, const float* __restrict__ attw,
+                                                             const float* __restrict__ scores, const float* __restrict__ lstm_logits,
+                                                             const float* __restrict__ dfinal, const float* __restrict__ dlat_cov,
+                                                             float* __restrict__ dhout, float* __restrict__ dlstm_logits,
+                                                             float* __restrict__ dlin_logits, float* __restrict__ part) {
+    __shared__ float red[4];
+    __shared__ float dl[64];
+    __shared__ float dav[128];
+    const int64_t w = blockIdx.x;
+    const int u = threadIdx.x, nwv = blockDim.x >> 6, nc = a.hi - a.lo;
+    const float temp = softplus_temp(a.att_temp[0]);
+    const float g = sigmoidf_(a.gate[0]);
+    float dgate_c = 0.f;
+    if (u < a.C) {
+        const float df = dfinal[w * a.C + u];
+        dl[u] = g * df;
+        dlstm_logits[w * a.C + u] = g * df;
+        dlin_logits[w * a.C + u] = (1.0f - g) * df;
+        dgate_c = df * (lstm_logits[w * a.C + u] - a.lin_logits[w * a.C + u]) * g * (1.0f - g);
+    }
+    const float dgate = block_sum(dgate_c, red, nwv);            // (also orders the dl[] writes)
+    float dlat = dlat_cov ? dlat_cov[w * a.H2 + u] : 0.f;
+    for (int c = 0; c < a.C; ++c) dlat = fmaf(dl[c], a.w_lin2[c * a.H2 + u], dlat);
+    for (int t = 0; t < nc; ++t) {
+        const float s = block_sum(dlat * a.hout[(w * a.T + a.lo + t) * a.H2 + u], red, nwv);
+        if (u == 0) dav[t] = s;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int t = 0; t < nc; ++t) dot = fmaf(attw[w * nc + t], dav[t], dot);
+    float dtemp = 0.f, dbatt = 0.f, dwatt = 0.f;
+    const float wa = a.w_att[u];
+    for (int t = 0; t < a.T; ++t) {
+        float dh = 0.f;
+        if (t >= a.lo && t < a.hi) {
+            const int tc = t - a.lo;
+            const float aw = attw[w * nc + tc];
+            const float ds = aw * (dav[tc] - dot);               // d loss / d score_t
+            const float hv = a.hout[(w * a.T + t) * a.H2 + u];
+            dh = aw * dlat + ds / temp * wa;
+            dwatt = fmaf(ds / temp, hv, dwatt);
+            dbatt += ds / temp;
+            dtemp -= ds * scores[w * nc + tc] / temp;
+        }
+        dhout[(w * a.T + t) * a.H2 + u] = dh;
+    }
+    const float raw = a.att_temp[0];
+    float* p = part + w * (a.H2 + 12);
+    p[u] = dwatt;
+    if (u < 12) {
+        float v = 0.f;
+        if (u == 0) v = dbatt;
+        if (u == 4) v = dgate;
+        if (u == 8) v = dtemp * (raw > 20.f ? 1.0f : sigmoidf_(raw));     // softplus'
+        p[a.H2 + u] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross entropy with class weights and label smoothing (nn.CrossEntropyLoss, reduction 'mean')
+// terms[w] = [ loss numerator of window w | w[y_w] ]
+// ---------------------------------------------------------------------------------------------
+__global__ void ce_terms_kernel(const float* __restrict__ logits, const int* __restrict__ labels, const float* __restrict__ cw,
+                                int64_t n, int C, float eps, float* __restrict__ terms) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const float* z = logits + w * C;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(z[c] - mx);
+    const float lse = mx + logf(den);
+    const int y = labels[w];
+    const float wy = cw ? cw[y] : 1.0f;
+    float smooth = 0.f;
+    for (int c = 0; c < C; ++c) smooth += (cw ? cw[c] : 1.0f) * (lse - z[c]);
+    terms[w * 2 + 0] = (1.0f - eps) * wy * (lse - z[y]) + (eps / (float)C) * smooth;
+    terms[w * 2 + 1] = wy;
+}
+// sums[0] = sum of numerators, sums[1] = sum of w[y]
+__global__ void ce_grad_kernel(const float* __restrict__ logits, const int* __restrict__ labels, const float* __restrict__ cw,
+                               const float* __restrict__ sums, int64_t n, int C, float eps, float* __restrict__ dlogits) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const float* z = logits + w * C;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(z[c] - mx);
+    const int y = labels[w];
+    const float wy = cw ? cw[y] : 1.0f;
+    float wsum = 0.f;
+    for (int c = 0; c < C; ++c) wsum += cw ? cw[c] : 1.0f;
+    const float inv = 1.0f / sums[1];
+    for (int c = 0; c < C; ++c) {
+        const float p = expf(z[c] - mx) / den;
+        const float wc = cw ? cw[c] : 1.0f;
+        dlogits[w * C + c] = ((1.0f - eps) * wy * (p - (c == y ? 1.0f : 0.f)) + (eps / (float)C) * (p * wsum - wc)) * inv;
+    }
+}
+
+// covariance penalty: raw Rc^T Rc (n x n) -> cov = cscale * it; G' = gscale * offdiag(cov), sq[i] = row sums of offdiag(cov)^2
+__global__ void cov_offdiag_kernel(const float* __restrict__ cov, int n, float cscale, float gscale, float* __restrict__ G,
+                                   float* __restrict__ sq) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float v = i == j ? 0.f : cov[i * n + j] * cscale;
+        G[i * n + j] = gscale * v;
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) sq[i] = s;
+}
+
+// rows x cols -> centred copy (column means removed); means from colsum
+__global__ void sub_colmean_kernel(const float* __restrict__ src, const float* __restrict__ colsum, int64_t rows, int cols,
+                                   float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) dst[i] = src[i] - colsum[i % cols] / (float)rows;
+}
+
+// deterministic column sums, two stages of fixed shape: stage 1 splits the rows into `chunks` contiguous
+// ranges (tmp [chunks][cols]), stage 2 adds the chunks in order.
+__global__ void colsum_stage1_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t ld, int chunks,
+                                     float* __restrict__ tmp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (c >= cols) return;
+    const int64_t per = (rows + chunks - 1) / chunks;
+    const int64_t r0 = ch * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += src[r * ld + c];
+    tmp[(int64_t)ch * cols + c] = s;
+}
+__global__ void colsum_stage2_kernel(const float* __restrict__ tmp, int cols, int chunks, float scale, float* __restrict__ dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) s += tmp[(int64_t)ch * cols + c];
+    dst[c] = s * scale;
+}
+
+__global__ void add_vec_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+__global__ void copy_vec_kernel(const float* __restrict__ a, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i];
+}
+
+// torch.optim.Adam (L2 weight decay added to the gradient); [wd_lo, wd_hi) uses wd_special (the gate group)
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 int64_t n, float lr_c1, float inv_sqrt_c2, float b1, float b2, float eps, float wd,
+                                 int64_t wd_lo, int64_t wd_hi, float wd_special) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float pw = p[i];
+    const float gi = g[i] + ((i >= wd_lo && i < wd_hi) ? wd_special : wd) * pw;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pw - lr_c1 * mi / (sqrtf(vi) * inv_sqrt_c2 + eps);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld, float* dst, int64_t rows_pad, hipStream_t st) {
+    const dim3 grid((unsigned)((rows_pad + 31) / 32), (unsigned)((cols + 31) / 32));
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, st, src, rows, cols, ld, dst, rows_pad);
+    return CHECK_LAUNCH();
+}
+
+static ExpandArgs make_expand_args(const TrainExpandParams& p) {
+    ExpandArgs a{};
+    a.proj = p.proj; a.tmat = p.tmat; a.lin_vec = p.lin_vec; a.b_bott = p.b_bott; a.ln_w = p.ln_w; a.ln_b = p.ln_b;
+    a.b_lin1 = p.b_lin1; a.T = p.T; a.Bn = p.Bn; a.NPROJ = p.NPROJ; a.C = p.C;
+    for (int k = 0; k < 3; ++k) a.key[k] = p.key[k];
+    a.thr = p.thr; a.scale = p.scale;
+    return a;
+}
+static int expand_block(const TrainExpandParams& p) { return (int)round_up(3 * p.Bn, 64); }
+
+size_t train_expand_lds_bytes(int T, int Bn, int NPROJ) {
+    const size_t fwd = ((size_t)T * NPROJ + 3 * (size_t)T * T + (size_t)T * 3 * Bn) * 4;
+    const size_t bwd = (3 * (size_t)T * T + (size_t)T * 3 * Bn + 12 * (size_t)T) * 4;
+    return fwd > bwd ? fwd : bwd;
+}
+
+int launch_train_expand_fwd(const TrainExpandParams& p, int64_t n_windows, float* Y, float* aug, float* lin_logits,
+                            hipStream_t st) {
+    const int block = expand_block(p);
+    if (block > 768 || p.C > 3 * p.Bn) return -1;
+    const size_t lds = ((size_t)p.T * p.NPROJ + 3 * (size_t)p.T * p.T + (size_t)p.T * 3 * p.Bn) * 4;
+    if (lds > 160 * 1024) return -1;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&train_expand_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return -2;
+        attr = true;
+    }
+    hipLaunchKernelGGL(train_expand_fwd_kernel, dim3((unsigned)n_windows), dim3(block), lds, st, make_expand_args(p), Y, aug,
+                       lin_logits);
+    return CHECK_LAUNCH();
+}
+
+int launch_train_expand_bwd(const TrainExpandParams& p, int64_t n_windows, const float* Y, const float* daug, const float* dlin,
+                            float* dproj, float* part, hipStream_t st) {
+    const int block = expand_block(p);
+    if (block > 768) return -1;
+    const size_t lds = (3 * (size_t)p.T * p.T + (size_t)p.T * 3 * p.Bn + 12 * (size_t)p.T) * 4;
+    if (lds > 160 * 1024) return -1;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&train_expand_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return -2;
+        attr = true;
+    }
+    hipLaunchKernelGGL(train_expand_bwd_kernel, dim3((unsigned)n_windows), dim3(block), lds, st, make_expand_args(p), Y, daug,
+                       dlin, dproj, part);
+    return CHECK_LAUNCH();
+}
+
+int launch_gelu_dropout(const float* Z, float* io, int64_t n, unsigned long long key, unsigned thr, float scale, int backward,
+                        hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (backward) hipLaunchKernelGGL(gelu_dropout_bwd_kernel, dim3(grid), dim3(256), 0, st, Z, io, n, key, thr, scale);
+    else hipLaunchKernelGGL(gelu_dropout_fwd_kernel, dim3(grid), dim3(256), 0, st, Z, io, n, key, thr, scale);
+    return CHECK_LAUNCH();
+}
+
+int launch_lstm_train_fwd(const float* gin, const float* w_hh, int h, int T, int64_t n_windows, float* act, float* cst,
+                          float* hout, hipStream_t st) {
+    const dim3 grid((unsigned)n_windows, 2);
+    if (h == 64) hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(256), 0, st, gin, w_hh, T, act, cst, hout);
+    else if (h == 128) hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(512), 0, st, gin, w_hh, T, act, cst, hout);
+    else return -1;
+    return CHECK_LAUNCH();
+}
+
+int launch_lstm_train_bwd(const float* dhout, const float* act, const float* cst, const float* hout, const float* w_hh, int h,
+                          int T, int64_t n_windows, float* dgin, float* hprev, hipStream_t st) {
+    const dim3 grid((unsigned)n_windows, 2);
+    if (h == 64) hipLaunchKernelGGL(lstm_train_bwd_kernel<64>, grid, dim3(256), 0, st, dhout, act, cst, hout, w_hh, T, dgin, hprev);
+    else if (h == 128) hipLaunchKernelGGL(lstm_train_bwd_kernel<128>, grid, dim3(512), 0, st, dhout, act, cst, hout, w_hh, T, dgin, hprev);
+    else return -1;
+    return CHECK_LAUNCH();
+}
+
+static PoolArgs make_pool_args(const TrainPoolParams& p) {
+    PoolArgs a{};
+    a.hout = p.hout; a.lin_logits = p.lin_logits; a.w_att = p.w_att; a.b_att = p.b_att; a.att_temp = p.att_temp;
+    a.w_lin2 = p.w_lin2; a.b_lin2 = p.b_lin2; a.gate = p.gate; a.T = p.T; a.H2 = p.H2; a.C = p.C; a.lo = p.lo; a.hi = p.hi;
+    return a;
+}
+
+int launch_pool_train_fwd(const TrainPoolParams& p, int64_t n_windows, float* attw, float* scores, float* latent,
+                          float* lstm_logits, float* final_logits, hipStream_t st) {
+    if (p.H2 % 64 || p.H2 > 256 || p.C > 64 || p.hi - p.lo > 128 || p.hi <= p.lo) return -1;
+    hipLaunchKernelGGL(pool_train_fwd_kernel, dim3((unsigned)n_windows), dim3(p.H2), 0, st, make_pool_args(p), attw, scores,
+                       latent, lstm_logits, final_logits);
+    return CHECK_LAUNCH();
+}
+
+int launch_pool_train_bwd(const TrainPoolParams& p, int64_t n_windows, const float* attw, const float* scores,
+                          const float* lstm_logits, const float* dfinal, const float* dlat_cov, float* dhout,
+                          float* dlstm_logits, float* dlin_logits, float* part, hipStream_t st) {
+    if (p.H2 % 64 || p.H2 > 256 || p.C > 64 || p.hi - p.lo > 128 || p.hi <= p.lo) return -1;
+    hipLaunchKernelGGL(pool_train_bwd_kernel, dim3((unsigned)n_windows), dim3(p.H2), 0, st, make_pool_args(p), attw, scores,
+                       lstm_logits, dfinal, dlat_cov, dhout, dlstm_logits, dlin_logits, part);
+    return CHECK_LAUNCH();
+}
+
+int launch_ce_terms(const float* logits, const int* labels, const float* cw, int64_t n, int C, float eps, float* terms,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(ce_terms_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, logits, labels, cw, n, C, eps, terms);
+    return CHECK_LAUNCH();
+}
+int launch_ce_grad(const float* logits, const int* labels, const float* cw, const float* sums, int64_t n, int C, float eps,
+                   float* dlogits, hipStream_t st) {
+    hipLaunchKernelGGL(ce_grad_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, logits, labels, cw, sums, n, C, eps,
+                       dlogits);
+    return CHECK_LAUNCH();
+}
+int launch_cov_offdiag(const float* cov, int n, float cscale, float gscale, float* G, float* sq, hipStream_t st) {
+    hipLaunchKernelGGL(cov_offdiag_kernel, dim3(n), dim3(64), 0, st, cov, n, cscale, gscale, G, sq);
+    return CHECK_LAUNCH();
+}
+int launch_sub_colmean(const float* src, const float* colsum, int64_t rows, int cols, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(sub_colmean_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, src, colsum, rows, cols, dst);
+    return CHECK_LAUNCH();
+}
+int launch_colsum(const float* src, int64_t rows, int cols, int64_t ld, float scale, float* tmp, float* dst, hipStream_t st) {
+    const int chunks = COLSUM_CHUNKS;
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((cols + 63) / 64, chunks), dim3(64), 0, st, src, rows, cols, ld, chunks, tmp);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 63) / 64), dim3(64), 0, st, tmp, cols, chunks, scale, dst);
+    return CHECK_LAUNCH();
+}
+int launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st) {
+    if (b) hipLaunchKernelGGL(add_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
+    else hipLaunchKernelGGL(copy_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, out, n);
+    return CHECK_LAUNCH();
+}
+int launch_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd, int64_t wd_lo, int64_t wd_hi,
+                     float wd_special, int step, hipStream_t st) {
+    const double b1 = 0.9, b2 = 0.999;
+    const float lr_c1 = (float)((double)lr / (1.0 - pow(b1, step)));
+    const float inv_sqrt_c2 = (float)(1.0 / sqrt(1.0 - pow(b2, step)));
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr_c1, inv_sqrt_c2,
+                       0.9f, 0.999f, 1e-8f, wd, wd_lo, wd_hi, wd_special);
+    return CHECK_LAUNCH();
+}

@@ -91,8 +91,16 @@ struct Gemm32Params {
     const float* bias;             // [N] or nullptr
     float* out; int64_t ldo;       // [M][ldo]
     int64_t M; int N; int N_alloc; int K;   // N % 4 == 0, K % 32 == 0
+    // split-K (head training's weight gradients: K = windows x seq_len, only a handful of output tiles):
+    // grid.z = splits, block z accumulates k in [z*K, (z+1)*K) of operands whose row strides are lda / ldw and
+    // writes its partial tile to out + z*split_stride (no bias); launch_splitk_reduce adds the partials in order.
+    int64_t ldw;          // row stride of W (0: K)
+    int splits;           // 0/1: plain GEMM
+    int64_t split_stride; // floats between partial outputs
 };
 int launch_gemm_f32(const Gemm32Params& p, int gelu, hipStream_t stream);
+// dst[i] = sum_z partial[z*stride + i], z ascending (deterministic), i < n
+int launch_splitk_reduce(const float* partial, int splits, int64_t stride, int64_t n, float* dst, hipStream_t stream);
 
 struct HeadDims {
     int I, C, T, Bn, L0, h;   // in_features, classes, seq_len, bottleneck dim, lin0 dim, lstm hidden
@@ -122,3 +130,52 @@ int launch_head_pool(const float* hout, const float* lin_logits, const HeadDims&
                      float b_att, float att_temp, const float* w_lin2, const float* b_lin2, float gate_sigmoid,
                      float temperature, int64_t n_windows, float* probs, float* logits, float* latent,
                      hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// classifier-head training (head_train_kernels.hip; orchestration in api_head_train.hip)
+// ---------------------------------------------------------------------------------------------
+constexpr int COLSUM_CHUNKS = 64;
+
+struct TrainExpandParams {
+    const float* proj;       // [w][T][NPROJ] per-position projections (cls | delta | acc | lin1 | pad)
+    const float* tmat;       // [3][T][T] temporal operators (EMA, delta o EMA, accel o EMA)
+    const float* lin_vec;    // [T] mean over the centre window of the EMA rows
+    const float *b_bott, *ln_w, *ln_b, *b_lin1;
+    int T, Bn, NPROJ, C;
+    unsigned long long key[3];   // dropout stream keys of the three bottlenecks for this step
+    unsigned thr;                // keep <=> hash24 >= thr
+    float scale;                 // 1 / (1 - p)
+};
+struct TrainPoolParams {
+    const float *hout, *lin_logits, *w_att, *b_att, *att_temp, *w_lin2, *b_lin2, *gate;
+    int T, H2, C, lo, hi;
+};
+
+// dst [cols][rows_pad] = src^T, columns rows..rows_pad zero-filled
+int launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld, float* dst, int64_t rows_pad, hipStream_t st);
+size_t train_expand_lds_bytes(int T, int Bn, int NPROJ);     // dynamic LDS the expand kernels need (<= 160 KiB)
+int launch_train_expand_fwd(const TrainExpandParams& p, int64_t n_windows, float* Y, float* aug, float* lin_logits, hipStream_t st);
+int launch_train_expand_bwd(const TrainExpandParams& p, int64_t n_windows, const float* Y, const float* daug, const float* dlin,
+                            float* dproj, float* part, hipStream_t st);
+int launch_gelu_dropout(const float* Z, float* io, int64_t n, unsigned long long key, unsigned thr, float scale, int backward,
+                        hipStream_t st);
+int launch_lstm_train_fwd(const float* gin, const float* w_hh, int h, int T, int64_t n_windows, float* act, float* cst,
+                          float* hout, hipStream_t st);
+int launch_lstm_train_bwd(const float* dhout, const float* act, const float* cst, const float* hout, const float* w_hh, int h,
+                          int T, int64_t n_windows, float* dgin, float* hprev, hipStream_t st);
+int launch_pool_train_fwd(const TrainPoolParams& p, int64_t n_windows, float* attw, float* scores, float* latent,
+                          float* lstm_logits, float* final_logits, hipStream_t st);
+int launch_pool_train_bwd(const TrainPoolParams& p, int64_t n_windows, const float* attw, const float* scores,
+                          const float* lstm_logits, const float* dfinal, const float* dlat_cov, float* dhout,
+                          float* dlstm_logits, float* dlin_logits, float* part, hipStream_t st);
+int launch_ce_terms(const float* logits, const int* labels, const float* cw, int64_t n, int C, float eps, float* terms,
+                    hipStream_t st);
+int launch_ce_grad(const float* logits, const int* labels, const float* cw, const float* sums, int64_t n, int C, float eps,
+                   float* dlogits, hipStream_t st);
+int launch_cov_offdiag(const float* cov, int n, float cscale, float gscale, float* G, float* sq, hipStream_t st);
+int launch_sub_colmean(const float* src, const float* colsum, int64_t rows, int cols, float* dst, hipStream_t st);
+// deterministic column sums of src [rows][cols] (row stride ld): dst[c] = scale * sum_r src[r][c]; tmp: COLSUM_CHUNKS * cols floats
+int launch_colsum(const float* src, int64_t rows, int cols, int64_t ld, float scale, float* tmp, float* dst, hipStream_t st);
+int launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st);      // b == nullptr: copy
+int launch_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd, int64_t wd_lo, int64_t wd_hi,
+                     float wd_special, int step, hipStream_t st);

@@ -78,7 +78,9 @@ class ClassifierLSTMDeltas:
         return self
 
     def state_dict(self):
-        return dict(self._weights or {})
+        """CPU torch tensors keyed like the reference module's state dict, so that
+        ``torch.save(model.state_dict(), ...)`` (workthreads.py:856) writes a loadable model.pth."""
+        return {k: torch.from_numpy(np.array(v, dtype=np.float32, copy=True)) for k, v in (self._weights or {}).items()}
 
     def to(self, device):
         device = torch.device(device)

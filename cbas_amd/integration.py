@@ -25,14 +25,17 @@ def install(strict: bool = True) -> bool:
     from .encoder import DinoEncoder
     from .head import ClassifierLSTMDeltas
     from .pipeline import encode_file, infer_file
+    from .train import train_lstm_model
 
     cbas._reference_DinoEncoder = getattr(cbas, "DinoEncoder", None)
     cbas._reference_encode_file = getattr(cbas, "encode_file", None)
     cbas._reference_infer_file = getattr(cbas, "infer_file", None)
+    cbas._reference_train_lstm_model = getattr(cbas, "train_lstm_model", None)
     classifier_head._reference_ClassifierLSTMDeltas = getattr(classifier_head, "ClassifierLSTMDeltas", None)
     cbas.DinoEncoder = DinoEncoder
     cbas.encode_file = encode_file
     cbas.infer_file = infer_file
+    cbas.train_lstm_model = train_lstm_model          # TrainingThread, workthreads.py:635
     classifier_head.ClassifierLSTMDeltas = ClassifierLSTMDeltas
     return True
 
@@ -40,7 +43,7 @@ def install(strict: bool = True) -> bool:
 def uninstall() -> None:
     cbas = importlib.import_module("cbas")
     classifier_head = importlib.import_module("classifier_head")
-    for mod, names in ((cbas, ("DinoEncoder", "encode_file", "infer_file")),
+    for mod, names in ((cbas, ("DinoEncoder", "encode_file", "infer_file", "train_lstm_model")),
                        (classifier_head, ("ClassifierLSTMDeltas",))):
         for n in names:
             ref = getattr(mod, "_reference_" + n, None)

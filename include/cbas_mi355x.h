@@ -49,7 +49,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   3
+#define CBAS_ABI_VERSION   4
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -188,6 +188,45 @@ int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_fra
 int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, int64_t first,
                               int64_t count, float temperature, float* probs_dev, float* logits_dev,
                               void* stream);
+
+/* ---- head training -------------------------------------------------------------------------
+ * Replaces the optimisation step inside train_lstm_model (backend/cbas.py:1326-1348):
+ *   optimizer.zero_grad(); final_logits, rawm = model(d)          (model.train(): dropout active)
+ *   loss = CrossEntropyLoss(weight, label_smoothing)(final_logits, l)
+ *        + sum(off_diagonal(cov(rawm))^2);   loss.backward();   optimizer.step()
+ * with optimizer = Adam([all but gate], [gate, weight_decay 1e-3], lr, weight_decay) (cbas.py:1305-1308).
+ * Forward, loss, backward and the Adam update all run on the device in fp32.  Dropout keep-masks come
+ * from a counter-based hash of (seed, step, layer, element), not from torch's RNG. */
+typedef struct cbas_head_trainer cbas_head_trainer;
+
+typedef struct cbas_train_config {
+    float    lr;               /* 1e-4 (cbas.py:1275)                                   */
+    float    weight_decay;     /* L2 added to the gradient, all parameters but gate     */
+    float    label_smoothing;  /* nn.CrossEntropyLoss(label_smoothing=...)              */
+    int32_t  max_batch;        /* largest number of windows per step (512)              */
+    uint64_t seed;             /* dropout stream seed                                   */
+    int32_t  dropout;          /* 1: Dropout(0.1) x3 + Dropout(0.15) as in train();  0: off */
+} cbas_train_config;
+
+/* weights_host: the same blob cbas_head_create takes.  class_weights_host: C floats or NULL. */
+int cbas_head_train_create(const cbas_head_config* cfg, const cbas_train_config* tcfg, const float* weights_host,
+                           int64_t n_weights, const float* class_weights_host, int device_id,
+                           cbas_head_trainer** out);
+void cbas_head_train_destroy(cbas_head_trainer* t);
+
+/* One optimisation step on a batch of n_windows (<= max_batch) explicit windows:
+ * x_dev (n_windows, seq_len, in_features) float32, labels_dev (n_windows) int32, both device pointers.
+ * loss_host (optional, 3 floats: total, cross-entropy, covariance penalty) is filled after a stream
+ * synchronisation; pass NULL to keep the step asynchronous.  update = 0 computes loss and gradients
+ * only (no Adam step; the step counter and the dropout stream do not advance). */
+int cbas_head_train_step(cbas_head_trainer* t, const float* x_dev, const int32_t* labels_dev, int32_t n_windows,
+                         int32_t update, float* loss_host, void* stream);
+
+/* Copy the current parameters (what = 0) or the gradients of the last step (what = 1) to the host, in the
+ * blob order of cbas_head_create (n = cbas_head_weights_count).  Synchronises the device. */
+int cbas_head_train_read(cbas_head_trainer* t, int32_t what, float* blob_host, int64_t n);
+/* Logits (n_windows, C) and latent (n_windows, 2h) of the LAST step's forward pass (device -> host). */
+int cbas_head_train_last_outputs(cbas_head_trainer* t, float* logits_host, float* latent_host, int32_t n_windows);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 
