@@ -95,3 +95,42 @@ def test_three_adam_steps(tag):
         got = like(wf[name], is_s)
         # after 3 Adam steps every weight has moved by <= 3 lr; agreement to a small fraction of that
         assert np.abs(got - ref).max() <= 0.05 * lr + 1e-6 * np.abs(ref).max(), (name, np.abs(got - ref).max())
+
+
+# ---- host side of cbas_amd.train (no GPU needed) --------------------------------------------------
+def test_pack_unpack_round_trip_and_initial_weights():
+    from cbas_amd.head import pack_head_weights
+    from cbas_amd.train import head_weight_names, initial_head_weights, unpack_head_weights
+    from cbas_amd.weights import head_param_shapes
+    for h, nl in ((64, 1), (128, 2)):
+        hcfg = C.HeadConfig(in_features=768, out_features=7, lstm_hidden_size=h, lstm_layers=nl)
+        w = initial_head_weights(hcfg, 5)
+        shapes = head_param_shapes(hcfg)
+        assert set(w) == set(shapes) == set(head_weight_names(hcfg))
+        assert all(tuple(w[k].shape) == tuple(shapes[k]) and w[k].dtype == np.float32 for k in w)
+        assert float(w["gate"]) == np.float32(0.2) and float(w["attention_temp"]) == 1.0     # classifier_head.py:89,94
+        assert np.all(w["cls_ln.weight"] == 1) and np.all(w["acc_ln.bias"] == 0)
+        bound = 1.0 / np.sqrt(768)                                                          # nn.Linear default init
+        assert np.abs(w["lin1.weight"]).max() <= bound and np.abs(w["lin1.weight"]).max() > 0.9 * bound
+        assert np.abs(w["lstm.weight_hh_l0"]).max() <= 1.0 / np.sqrt(h)                     # nn.LSTM default init
+        blob = pack_head_weights(hcfg, w)
+        back = unpack_head_weights(hcfg, blob)
+        assert all(np.array_equal(back[k], w[k]) for k in w)
+        w2 = initial_head_weights(hcfg, 5)
+        assert all(np.array_equal(w2[k], w[k]) for k in w)                                  # seeded: reproducible
+
+
+def test_collate_drops_failed_samples():
+    from cbas_amd.train import collate_fn
+    batch = [(torch.zeros(31, 8), torch.tensor(2)), (torch.zeros(31, 8), torch.tensor(-1)), (torch.ones(31, 8), torch.tensor(0))]
+    d, l = collate_fn(batch)
+    assert d.shape == (2, 31, 8) and l.tolist() == [2, 0]
+    d, l = collate_fn([(torch.zeros(31, 8), torch.tensor(-1))])
+    assert d.numel() == 0 and l.numel() == 0
+
+
+def test_trainer_refuses_cpu_device():
+    from cbas_amd.train import HeadTrainer
+    hcfg = C.HeadConfig(in_features=768, out_features=9)
+    with pytest.raises(RuntimeError, match="GPU"):
+        HeadTrainer(hcfg, W.synth_head_weights(hcfg, 1), "cpu")
