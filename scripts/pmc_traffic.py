@@ -46,6 +46,23 @@ def main() -> None:
         per[k] = {"launches": fn[k],
                   "fetch_bytes_per_launch": int(ft[k] / fn[k] * 1024 * 2),
                   "write_bytes_per_launch": int(wt.get(k, 0.0) / max(1, wn.get(k, 1)) * 1024)}
+    if len(sys.argv) > 4:
+        # optional third pass: --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE.  The counter sums the busy cycles of
+        # all 1024 MFMA pipes (256 CUs x 4 SIMDs); utilisation is quoted against the 2.4 GHz peak clock over the
+        # kernel's wall time, i.e. the same normalisation as the 2.5 PFLOP/s roofline peak.
+        busy, dur, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
+        with open(sys.argv[4], newline="") as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                if k and row["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    busy[k] += float(row["Counter_Value"])
+                    dur[k] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                    cnt[k] += 1
+        for k in per:
+            if cnt.get(k):
+                per[k]["mfma_busy_cycles_per_launch"] = int(busy[k] / cnt[k])
+                per[k]["avg_ns_in_pmc_pass"] = int(dur[k] / cnt[k])
+                per[k]["mfma_util_vs_2.4GHz_peak"] = round(busy[k] / 1024.0 / (dur[k] * 2.4), 4)
     gemm = [k for k in per if k.startswith("gemm_f16")]
     g_n = sum(per[k]["launches"] for k in gemm)
     g_b = sum(per[k]["launches"] * (per[k]["fetch_bytes_per_launch"] + per[k]["write_bytes_per_launch"]) for k in gemm)
