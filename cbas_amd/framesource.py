@@ -1,0 +1,233 @@
+"""Frame sources for ``encode_file`` beyond ``decord``.
+
+The reference decodes with ``decord.VideoReader(path).get_batch(range)`` (backend/cbas.py:402,425) and
+keeps only the green plane (``frames[:, :, :, 1] / 255``, cbas.py:431).  Two sources that deliver exactly
+that plane, one byte per pixel, without any Python video package:
+
+* ``Y4MFileSource``  - an uncompressed YUV4MPEG2 file (mono or planar YUV; the first plane is used),
+  memory-mapped, random access.  Registered for ``.y4m``.
+* ``PipeFrameSource`` - an external decoder process (by default ``ffmpeg ... -vf extractplanes=g -pix_fmt
+  gray -f yuv4mpegpipe -``) streaming Y4M over a pipe.  A reader thread decodes ahead into a bounded
+  queue, so decode, the pinned-host -> HBM copy (``cbas_enc_submit_u8_host``) and the ViT overlap.
+  The frame count comes from a probe command (``ffprobe -count_packets``) because ``encode_file``
+  reports progress and the container's count is what the reference's ``len(reader)`` returns.
+
+Both return uint8 ``(n, H, W)`` green planes from ``get_batch(range)``; ``DinoEncoder.submit_host`` takes
+that layout directly (50 KB per 224x224 frame over PCIe instead of 150 KB).
+"""
+from __future__ import annotations
+
+import os
+import queue
+import subprocess
+import threading
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_Y4M_MAGIC = b"YUV4MPEG2"
+
+
+def _parse_y4m_header(line: bytes):
+    """'YUV4MPEG2 W224 H224 F10:1 Ip A1:1 Cmono' -> (width, height, bytes per frame)."""
+    parts = line.strip().split()
+    if not parts or parts[0] != _Y4M_MAGIC:
+        raise ValueError(f"not a YUV4MPEG2 stream (starts with {line[:16]!r})")
+    w = h = None
+    cs = b"420"
+    for p in parts[1:]:
+        if p[:1] == b"W":
+            w = int(p[1:])
+        elif p[:1] == b"H":
+            h = int(p[1:])
+        elif p[:1] == b"C":
+            cs = p[1:]
+    if not w or not h:
+        raise ValueError(f"Y4M header lacks W/H: {line!r}")
+    if cs.startswith(b"mono"):
+        fsize = w * h
+    elif cs.startswith(b"420"):
+        fsize = w * h + 2 * (((w + 1) // 2) * ((h + 1) // 2))
+    elif cs.startswith(b"422"):
+        fsize = w * h + 2 * (((w + 1) // 2) * h)
+    elif cs.startswith(b"444"):
+        fsize = 3 * w * h
+    else:
+        raise ValueError(f"unsupported Y4M colour space {cs!r}")
+    if cs[-2:] in (b"10", b"12", b"16"):
+        raise ValueError(f"only 8-bit Y4M is supported (got {cs!r})")
+    return w, h, fsize
+
+
+def write_y4m(path: str, planes: np.ndarray, fps: int = 10) -> None:
+    """Write uint8 (N,H,W) planes as a mono Y4M file (test clips; ``ffmpeg -i x.mp4 -vf extractplanes=g
+    -pix_fmt gray x.y4m`` produces the same layout from a real video)."""
+    planes = np.ascontiguousarray(planes, dtype=np.uint8)
+    n, h, w = planes.shape
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F%d:1 Ip A1:1 Cmono\n" % (w, h, fps))
+        for i in range(n):
+            f.write(b"FRAME\n")
+            f.write(planes[i].tobytes())
+
+
+class Y4MFileSource:
+    """Random-access reader of an uncompressed .y4m file; the first plane of every frame is returned."""
+
+    def __init__(self, path: str):
+        with open(path, "rb") as f:
+            head = f.readline(256)
+            self.width, self.height, self._fsize = _parse_y4m_header(head)
+            self._data0 = len(head)
+            marker = f.readline(256)
+        if not marker.startswith(b"FRAME"):
+            size = os.path.getsize(path)
+            if size == self._data0:
+                self._n, self._stride, self._mm = 0, 0, None
+                return
+            raise ValueError(f"{path}: no FRAME marker after the Y4M header")
+        self._marker = len(marker)                   # constant when the frames carry no parameters (ffmpeg's output)
+        self._stride = self._marker + self._fsize
+        size = os.path.getsize(path) - self._data0
+        if size % self._stride:
+            raise ValueError(f"{path}: size is not a whole number of {self._stride}-byte frames (per-frame parameters?)")
+        self._n = size // self._stride
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r", offset=self._data0, shape=(self._n, self._stride))
+
+    def __len__(self):
+        return self._n
+
+    def get_batch(self, indices) -> np.ndarray:
+        idx = list(indices)
+        hw = self.width * self.height
+        if not idx:
+            return np.empty((0, self.height, self.width), np.uint8)
+        if idx == list(range(idx[0], idx[0] + len(idx))):
+            rows = self._mm[idx[0]:idx[0] + len(idx), self._marker:self._marker + hw]
+        else:
+            rows = self._mm[idx][:, self._marker:self._marker + hw]
+        return np.ascontiguousarray(rows).reshape(len(idx), self.height, self.width)
+
+
+class PipeFrameSource:
+    """Sequential frames from an external decoder writing Y4M to its stdout."""
+
+    DECODE_CMD: Sequence[str] = ("ffmpeg", "-v", "error", "-i", "{path}", "-vf", "extractplanes=g", "-pix_fmt", "gray",
+                                 "-f", "yuv4mpegpipe", "-")
+    PROBE_CMD: Sequence[str] = ("ffprobe", "-v", "error", "-select_streams", "v:0", "-count_packets", "-show_entries",
+                                "stream=nb_read_packets", "-of", "csv=p=0", "{path}")
+
+    def __init__(self, path: str, decode_cmd: Optional[Sequence[str]] = None, probe_cmd: Optional[Sequence[str]] = None,
+                 n_frames: Optional[int] = None, prefetch_frames: int = 512, queue_depth: int = 3):
+        self.path = path
+        fmt = lambda cmd: [a.replace("{path}", path) for a in cmd]     # noqa: E731
+        if n_frames is None:
+            out = subprocess.run(fmt(probe_cmd or self.PROBE_CMD), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+            n_frames = int(out.stdout.decode().strip().split(",")[0] or 0)
+        self._n = int(n_frames)
+        self._next = 0
+        self._prefetch = int(prefetch_frames)
+        self._q: "queue.Queue" = queue.Queue(maxsize=queue_depth)
+        self._pending: List[np.ndarray] = []
+        self._proc = subprocess.Popen(fmt(decode_cmd or self.DECODE_CMD), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      bufsize=1 << 20)
+        head = self._proc.stdout.readline(256)
+        if not head and self._n == 0:
+            self.width = self.height = 0
+            self._fsize = 0
+        else:
+            try:
+                self.width, self.height, self._fsize = _parse_y4m_header(head)
+            except ValueError as e:
+                err = self._proc.stderr.read().decode(errors="replace")
+                self.close()
+                raise RuntimeError(f"decoder for {path!r} did not produce a Y4M stream: {e}; stderr: {err[-400:]}") from e
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._pump, name="cbas-decode", daemon=True)
+        self._thread.start()
+
+    # reader thread: decode ahead of the consumer
+    def _pump(self):
+        hw = self.width * self.height
+        try:
+            while not self._stop.is_set():
+                buf = np.empty((self._prefetch, self.height, self.width), np.uint8)
+                k = 0
+                while k < self._prefetch:
+                    marker = self._proc.stdout.readline(256)
+                    if not marker:
+                        break
+                    if not marker.startswith(b"FRAME"):
+                        raise ValueError(f"Y4M stream out of sync: {marker[:16]!r}")
+                    data = self._proc.stdout.read(self._fsize)
+                    if len(data) < self._fsize:
+                        raise ValueError("Y4M stream truncated inside a frame")
+                    buf[k] = np.frombuffer(data, np.uint8, hw).reshape(self.height, self.width)
+                    k += 1
+                if k:
+                    self._put(buf[:k])
+                if k < self._prefetch:
+                    break
+            self._put(None)
+        except Exception as e:  # noqa: BLE001   surfaced to the consumer by get_batch
+            self._put(e)
+
+    def _put(self, item):
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
+
+    def __len__(self):
+        return self._n
+
+    def get_batch(self, indices) -> np.ndarray:
+        idx = list(indices)
+        if not idx:
+            return np.empty((0, self.height, self.width), np.uint8)
+        if idx != list(range(self._next, self._next + len(idx))):
+            raise ValueError(f"PipeFrameSource is sequential: expected frames from {self._next}, got {idx[0]}..{idx[-1]}")
+        need, parts = len(idx), []
+        while need > 0:
+            if not self._pending:
+                item = self._q.get()
+                if item is None:
+                    raise EOFError(f"{self.path}: decoder delivered {self._next + len(idx) - need} frames, container reports {self._n}")
+                if isinstance(item, Exception):
+                    raise item
+                self._pending.append(item)
+            cur = self._pending[0]
+            take = min(need, cur.shape[0])
+            parts.append(cur[:take])
+            if take == cur.shape[0]:
+                self._pending.pop(0)
+            else:
+                self._pending[0] = cur[take:]
+            need -= take
+        self._next += len(idx)
+        return parts[0] if len(parts) == 1 and parts[0].flags.c_contiguous else np.concatenate(parts)
+
+    def close(self):
+        if getattr(self, "_stop", None) is not None:
+            self._stop.set()
+        p = getattr(self, "_proc", None)
+        if p is not None:
+            try:
+                p.kill()
+            except OSError:
+                pass
+            for s in (p.stdout, p.stderr):
+                try:
+                    s.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            p.wait()
+            self._proc = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

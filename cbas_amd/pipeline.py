@@ -13,6 +13,7 @@ once per materialised window.
 from __future__ import annotations
 
 import os
+import shutil
 import traceback
 from collections import deque
 from typing import Callable, List, Optional
@@ -22,6 +23,7 @@ import torch
 
 from . import _lib, h5io
 from .encoder import DinoEncoder
+from .framesource import PipeFrameSource, Y4MFileSource
 from .head import ClassifierLSTMDeltas, from_reference_module
 
 CHUNK_SIZE = 512                     # backend/cbas.py:48
@@ -73,7 +75,7 @@ class _DecordSource:
         return self._r.get_batch(indices).asnumpy()             # backend/cbas.py:425
 
 
-_READERS = {".npy": NpyFrameSource}
+_READERS = {".npy": NpyFrameSource, ".y4m": Y4MFileSource}
 
 
 def register_reader(ext: str, factory: Callable[[str], object]) -> None:
@@ -87,8 +89,10 @@ def open_video(path: str):
     try:
         return _DecordSource(path)
     except ImportError as e:
-        raise RuntimeError(f"no frame source for {path!r}: decord is not installed and no reader is registered "
-                           f"for {ext!r}") from e
+        if shutil.which("ffmpeg") and shutil.which("ffprobe"):
+            return PipeFrameSource(path)            # decoder process + reader thread (cbas_amd/framesource.py)
+        raise RuntimeError(f"no frame source for {path!r}: decord is not installed, ffmpeg/ffprobe are not on PATH and "
+                           f"no reader is registered for {ext!r}") from e
 
 
 # ------------------------------------------------------------------------------------------------
@@ -117,7 +121,16 @@ def encode_file(encoder: DinoEncoder, path: str, progress_callback=None, reader=
     if not isinstance(encoder, DinoEncoder):
         raise TypeError("cbas_amd.encode_file needs a cbas_amd.DinoEncoder (the MI355X encoder); "
                         f"got {type(encoder).__name__}")
+    own_reader = reader is None
     reader = reader if reader is not None else open_video(path)     # reader errors propagate (cbas.py:400-402)
+    try:
+        return _encode_from_reader(encoder, path, reader, progress_callback)
+    finally:
+        if own_reader and hasattr(reader, "close"):
+            reader.close()
+
+
+def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callback) -> Optional[str]:
     video_len = len(reader)
     if video_len == 0:
         print(f"Warning: Video {path} contains no frames. Skipping.")

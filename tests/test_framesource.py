@@ -1,0 +1,95 @@
+"""Frame sources of cbas_amd/framesource.py: Y4M files and a decoder process on a pipe."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from cbas_amd import framesource as FS, synth
+
+
+def planes(n=70, h=32, w=48, seed=3):
+    return np.ascontiguousarray(synth.noise_frames(seed, n, h, w)[:, :, :, 1])
+
+
+def test_y4m_file_round_trip(tmp_path):
+    g = planes()
+    p = str(tmp_path / "clip.y4m")
+    FS.write_y4m(p, g)
+    src = FS.Y4MFileSource(p)
+    assert len(src) == 70 and (src.height, src.width) == (32, 48)
+    assert np.array_equal(src.get_batch(range(0, 70)), g)
+    assert np.array_equal(src.get_batch([5, 9, 2]), g[[5, 9, 2]])
+    assert src.get_batch(range(0)).shape == (0, 32, 48)
+
+
+def test_y4m_420_takes_the_first_plane(tmp_path):
+    g = planes(5, 16, 16)
+    p = str(tmp_path / "c420.y4m")
+    with open(p, "wb") as f:
+        f.write(b"YUV4MPEG2 W16 H16 F10:1 Ip A1:1 C420jpeg\n")
+        for i in range(5):
+            f.write(b"FRAME\n" + g[i].tobytes() + bytes(128))
+    assert np.array_equal(FS.Y4MFileSource(p).get_batch(range(5)), g)
+
+
+def test_y4m_rejects_garbage(tmp_path):
+    p = str(tmp_path / "bad.y4m")
+    open(p, "wb").write(b"RIFF....AVI ")
+    with pytest.raises(ValueError):
+        FS.Y4MFileSource(p)
+
+
+def _pipe_source(path, n, **kw):
+    cat = [sys.executable, "-c", "import sys,shutil; shutil.copyfileobj(open(sys.argv[1],'rb'), sys.stdout.buffer)", "{path}"]
+    probe = [sys.executable, "-c", f"print({n})"]
+    return FS.PipeFrameSource(path, decode_cmd=cat, probe_cmd=probe, **kw)
+
+
+def test_pipe_source_streams_in_order_with_prefetch(tmp_path):
+    g = planes(200)
+    p = str(tmp_path / "clip.y4m")
+    FS.write_y4m(p, g)
+    src = _pipe_source(p, 200, prefetch_frames=64, queue_depth=2)
+    assert len(src) == 200
+    got = [src.get_batch(range(i, min(i + 48, 200))) for i in range(0, 200, 48)]     # batch size unrelated to prefetch size
+    assert np.array_equal(np.concatenate(got), g)
+    with pytest.raises(ValueError):
+        src.get_batch(range(10, 20))          # sequential only
+    src.close()
+
+
+def test_pipe_source_reports_short_streams_and_bad_decoders(tmp_path):
+    g = planes(20)
+    p = str(tmp_path / "clip.y4m")
+    FS.write_y4m(p, g)
+    src = _pipe_source(p, 25)                 # container claims more frames than the decoder delivers
+    src.get_batch(range(0, 20))
+    with pytest.raises(EOFError):
+        src.get_batch(range(20, 25))
+    src.close()
+    with pytest.raises(RuntimeError, match="Y4M"):
+        FS.PipeFrameSource(p, decode_cmd=[sys.executable, "-c", "print('not a video')"], n_frames=3)
+
+
+@pytest.mark.gpu
+def test_encode_file_from_y4m_and_pipe_equals_npy(tmp_path):
+    """The same clip through the three sources gives byte-identical _cls.h5 rows."""
+    import torch
+    from cbas_amd import config as C, h5io, pipeline as P, weights as W
+    from cbas_amd.encoder import DinoEncoder
+    cfg = C.VIT_TINY
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=16, max_frame=(64, 64))
+    rgb = synth.cage_frames(4, 90, 64, 64)
+    npy = str(tmp_path / "a.npy"); np.save(npy, rgb)
+    y4m = str(tmp_path / "b.y4m"); FS.write_y4m(y4m, rgb[:, :, :, 1])
+    y4m2 = str(tmp_path / "c.y4m"); FS.write_y4m(y4m2, rgb[:, :, :, 1])
+    def rows(path):
+        with h5io.ClsReader(path) as r:
+            return r.read(0, r.shape[0])
+
+    ref = rows(P.encode_file(enc, npy))
+    got = rows(P.encode_file(enc, y4m))
+    got2 = rows(P.encode_file(enc, y4m2, reader=_pipe_source(y4m2, 90, prefetch_frames=32)))
+    enc.close()
+    assert ref.shape == (90, cfg.hidden_size) and np.array_equal(ref, got) and np.array_equal(ref, got2)
