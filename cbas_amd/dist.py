@@ -130,3 +130,74 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# One long clip on N GPUs (last sentence): contiguous frame ranges per rank; the head's
+# window of frame i needs CLS rows i-half .. i+half, so neighbouring ranks exchange `half` = seq_len // 2
+# rows at each cut.  This is the one real exchange step of the path: 15 rows x 768 fp16 = 23 KB per cut.
+# ------------------------------------------------------------------------------------------------
+def shard_frames(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
+    """Balanced contiguous ranges: rank r encodes frames [start, stop)."""
+    base, extra = divmod(n_frames, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def exchange_halo(rows: torch.Tensor, half: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``rows`` = this rank's (n_local, D) CLS rows of its contiguous frame range (ranks in frame order).
+    Returns (left, right): up to ``half`` rows preceding / following the range, taken from as many
+    neighbouring ranks as needed (a rank may hold fewer than ``half`` frames); empty at the clip's ends.
+
+    One all_gather of a fixed (2*half + 1, D)-shaped block per rank: its first and last min(n_local, half)
+    rows and n_local (the blocks are tiny, so the all_gather is cheaper than a send/recv schedule)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    D = rows.shape[1]
+    if world == 1 or half == 0:
+        return rows[:0], rows[:0]
+    gloo = dist.get_backend() == "gloo"
+    src = rows.cpu() if gloo else rows
+    n = src.shape[0]
+    k = min(n, half)
+    blk = torch.zeros((2 * half + 1, D), dtype=torch.float32, device=src.device)
+    if k:
+        blk[:k] = src[:k].float()                    # head rows (fp16 -> fp32 is exact)
+        blk[half:half + k] = src[n - k:].float()     # tail rows
+    blk[2 * half, 0] = float(n)                      # row count (exact in fp32 up to 2^24 frames per rank)
+    allb = [torch.empty_like(blk) for _ in range(world)]
+    dist.all_gather(allb, blk)
+    counts = [int(b[2 * half, 0].item()) for b in allb]
+
+    def collect(order, take_tail: bool):
+        parts, need = [], half
+        for r in order:
+            if need <= 0:
+                break
+            kr = min(counts[r], half)
+            if kr == 0:
+                continue
+            t = allb[r][half:half + kr] if take_tail else allb[r][:kr]
+            take = min(need, kr)
+            parts.append(t[kr - take:] if take_tail else t[:take])
+            need -= take
+        return parts
+
+    left_parts = collect(range(rank - 1, -1, -1), True)          # nearest neighbour first
+    right_parts = collect(range(rank + 1, world), False)
+    left = torch.cat(left_parts[::-1]) if left_parts else blk[:0]
+    right = torch.cat(right_parts) if right_parts else blk[:0]
+    return left.to(rows.dtype).to(rows.device), right.to(rows.dtype).to(rows.device)
+
+
+def classify_sharded(head, local_cls16: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
+    """Probabilities (n_local, C) for this rank's frame range of ONE clip split by ``shard_frames``:
+    halo exchange, then the range form of the head (windows clamp only at the true clip ends)."""
+    half = head.seq_len // 2
+    left, right = exchange_halo(local_cls16, half)
+    buf = torch.cat([left, local_cls16, right]).contiguous()
+    n_local = local_cls16.shape[0]
+    probs = torch.empty((buf.shape[0], head.out_features), dtype=torch.float32, device=buf.device)
+    if n_local:
+        head.infer_range_into(buf, buf.shape[0], left.shape[0], n_local, probs, temperature)
+    return probs[left.shape[0]:left.shape[0] + n_local]
