@@ -188,7 +188,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const int r = it * 8 + (lane >> 3), c = lane & 7;      // 8 rows x 128 bytes per wave store
                 const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = row_base + half * 64 + r;
-                if (m < p.M) *reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8) = hv;
+                if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
             }
             asm volatile("" ::: "memory");
         }
