@@ -46,6 +46,10 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     "cbas_enc_submit_u8_host": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64]),
     "cbas_enc_wait": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "cbas_enc_submit_u8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p,
+                                   c_void_p, c_void_p]),
+    "cbas_enc_wait_stream": (c_int, [c_void_p, c_int, c_void_p]),
+    "cbas_enc_set_lanes": (c_int, [c_void_p, c_int]),
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int, c_int]),
     "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),

@@ -42,9 +42,10 @@ struct Slot {
     float* out32_host = nullptr;
     f16* out16_dev = nullptr;
     float* out32_dev = nullptr;
-    hipEvent_t ev_copied = nullptr, ev_done = nullptr;
+    hipEvent_t ev_copied = nullptr, ev_done = nullptr, ev_in = nullptr;
     int n = 0;
     bool busy = false;
+    bool dev_mode = false;        // submitted by cbas_enc_submit_u8 (device in/out) rather than ..._host
 };
 
 }  // namespace
@@ -73,11 +74,14 @@ struct cbas_enc {
     hipStream_t compute = nullptr, copy = nullptr;
     Slot slots[CBAS_ENC_SLOTS];
     int64_t slot_pixels = 0;
-    // lane 0 = the buffers above; lane 1 = a second set for the two-stream split of a batch
-    struct Lane { f16 *A_patch, *h16, *qkv16, *u16; float* x; hipStream_t stream; hipEvent_t done; };
+    // Two batches in flight: the asynchronous entry points (cbas_enc_submit_u8 / ..._host) alternate two
+    // compute lanes, each a full workspace + its own stream, so that one batch's partial tile rounds,
+    // LayerNorm and attention run under the other batch's GEMMs (+10 % measured; outputs bit-identical).
+    // lane 0 = the buffers above on `compute`; the synchronous cbas_enc_forward_* always use lane 0.
+    struct Lane { f16 *A_patch, *h16, *qkv16, *u16; float* x; hipStream_t stream; };
     Lane lanes[2] = {};
-    hipEvent_t ev_fork = nullptr;
-    bool dual_lanes = false;
+    int n_lanes = 1;
+    uint64_t submit_count = 0;
     // optional per-kernel-category timing (HIP events on the launch stream)
     bool prof_on = false;
     struct ProfRec { hipEvent_t a, b; int cat; double flops; };
@@ -156,7 +160,8 @@ int ensure_pos_embed(cbas_enc* h, int nh, int nw, hipStream_t stream) {
                 }
             }
     }
-    HIP_TRY(hipStreamSynchronize(stream));
+    (void)stream;
+    HIP_TRY(hipDeviceSynchronize());       // first use of a resolution: the other lane may still read the old table
     HIP_TRY(hipMemcpy(h->pos_tab, out.data(), out.size() * 4, hipMemcpyHostToDevice));
     h->rope_nh = nh;
     h->rope_nw = nw;
@@ -187,7 +192,8 @@ int ensure_rope(cbas_enc* h, int nh, int nw, hipStream_t stream) {
             }
         }
     // synchronous copies (first use of a resolution only); the source vectors die at return
-    HIP_TRY(hipStreamSynchronize(stream));
+    (void)stream;
+    HIP_TRY(hipDeviceSynchronize());       // first use of a resolution: the other lane may still read the old table
     HIP_TRY(hipMemcpy(h->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
     h->rope_nh = nh;
@@ -315,31 +321,8 @@ int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int wi
     if (rc) return rc;
     if (!frames_dev) return cbas_fail(CBAS_EINVAL, "frames_dev is NULL");
     HIP_TRY(hipSetDevice(h->device));
-    const bool split = h->dual_lanes && stop_layer < 0 && n >= 16;
-    if (!split)
-        return forward_u8_one(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32,
-                              cls_f16, st, stop_layer, stop_stage);
-    // Two half-batches on two internal streams: one half's kernel tails, LayerNorm, attention and
-    // epilogues overlap the other half's GEMM main loops.  Results are bit-identical to the
-    // single-lane order (rows are independent).
-    rc = ensure_rope(h, height / h->cfg.patch_size, width / h->cfg.patch_size, st);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev_fork, st));
-    const int n0 = (n + 1) / 2;
-    for (int l = 0; l < 2; ++l) {
-        const int off = l ? n0 : 0, cnt = l ? n - n0 : n0;
-        hipStream_t ls = h->lanes[l].stream;
-        HIP_TRY(hipStreamWaitEvent(ls, h->ev_fork, 0));
-        use_lane(h, l);
-        rc = forward_u8_one(h, frames_dev + (int64_t)off * frame_stride, cnt, height, width, frame_stride, row_stride,
-                            pixel_stride, cls_f32 ? cls_f32 + (int64_t)off * h->D : nullptr,
-                            cls_f16 ? cls_f16 + (int64_t)off * h->D : nullptr, ls, -1, -1);
-        if (rc) { use_lane(h, 0); return rc; }
-        HIP_TRY(hipEventRecord(h->lanes[l].done, ls));
-        HIP_TRY(hipStreamWaitEvent(st, h->lanes[l].done, 0));
-    }
-    use_lane(h, 0);
-    return CBAS_OK;
+    return forward_u8_one(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32, cls_f16, st,
+                          stop_layer, stop_stage);
 }
 
 }  // namespace
@@ -360,15 +343,12 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
         if (s.out32_dev) (void)hipFree(s.out32_dev);
         if (s.ev_copied) (void)hipEventDestroy(s.ev_copied);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
     }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (h->lanes[0].x) { h->A_patch = h->lanes[0].A_patch; h->x = h->lanes[0].x; h->h16 = h->lanes[0].h16;
                          h->qkv16 = h->lanes[0].qkv16; h->u16 = h->lanes[0].u16; }
-    for (int l = 0; l < 2; ++l) {
-        if (h->lanes[l].stream) { (void)hipStreamSynchronize(h->lanes[l].stream); (void)hipStreamDestroy(h->lanes[l].stream); }
-        if (h->lanes[l].done) (void)hipEventDestroy(h->lanes[l].done);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->lanes[1].stream) { (void)hipStreamSynchronize(h->lanes[1].stream); (void)hipStreamDestroy(h->lanes[1].stream); }
     {
         void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16};
         for (void* b : b1) if (b) (void)hipFree(b);
@@ -524,33 +504,25 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->u16, 0, h->rows_cap * F * sizeof(f16), st));
-    // second lane (half-batch overlap on two streams).  Measured on MI355X it LOSES 15-40 % (blocks
-    // with 64-128 KiB of LDS cannot co-reside, the two kernels only evict each other's operands), so
-    // it is off unless CBAS_DUAL_LANES=1 asks for the experiment.
+    // second compute lane (see cbas_enc::Lane); CBAS_LANES=1 keeps a single lane
     {
-        const char* e = getenv("CBAS_DUAL_LANES");
-        h->dual_lanes = (e && e[0] == '1');
+        const char* e = getenv("CBAS_LANES");
+        h->n_lanes = (e && atoi(e) == 1) ? 1 : 2;
         cbas_enc::Lane& L0 = h->lanes[0];
-        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16;
-        if (h->dual_lanes) {
+        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16; L0.stream = h->compute;
+        if (h->n_lanes == 2) {
             cbas_enc::Lane& L1 = h->lanes[1];
-            const int64_t rows1 = round_up(((int64_t)c.max_batch / 2 + 1) * Tmax, 128);
-            const int64_t prow1 = round_up(((int64_t)c.max_batch / 2 + 1) * Pmax, 128);
-            CREATE_TRY(hipMalloc(&L1.A_patch, prow1 * 512 * sizeof(f16)));
-            CREATE_TRY(hipMalloc(&L1.x, rows1 * D * sizeof(float)));
-            CREATE_TRY(hipMalloc(&L1.h16, rows1 * D * sizeof(f16)));
-            CREATE_TRY(hipMalloc(&L1.qkv16, rows1 * 3 * D * sizeof(f16)));
-            CREATE_TRY(hipMalloc(&L1.u16, rows1 * F * sizeof(f16)));
-            CREATE_TRY(hipMemsetAsync(L1.A_patch, 0, prow1 * 512 * sizeof(f16), st));
-            CREATE_TRY(hipMemsetAsync(L1.x, 0, rows1 * D * sizeof(float), st));
-            CREATE_TRY(hipMemsetAsync(L1.h16, 0, rows1 * D * sizeof(f16), st));
-            CREATE_TRY(hipMemsetAsync(L1.qkv16, 0, rows1 * 3 * D * sizeof(f16), st));
-            CREATE_TRY(hipMemsetAsync(L1.u16, 0, rows1 * F * sizeof(f16), st));
-            for (int l = 0; l < 2; ++l) {
-                CREATE_TRY(hipStreamCreateWithFlags(&h->lanes[l].stream, hipStreamNonBlocking));
-                CREATE_TRY(hipEventCreateWithFlags(&h->lanes[l].done, hipEventDisableTiming));
-            }
-            CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            CREATE_TRY(hipMalloc(&L1.A_patch, h->prow_cap * 512 * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.x, h->rows_cap * D * sizeof(float)));
+            CREATE_TRY(hipMalloc(&L1.h16, h->rows_cap * D * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.qkv16, h->rows_cap * 3 * D * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.u16, h->rows_cap * F * sizeof(f16)));
+            CREATE_TRY(hipMemsetAsync(L1.A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.x, 0, h->rows_cap * D * sizeof(float), st));
+            CREATE_TRY(hipMemsetAsync(L1.h16, 0, h->rows_cap * D * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.u16, 0, h->rows_cap * F * sizeof(f16), st));
+            CREATE_TRY(hipStreamCreateWithFlags(&L1.stream, hipStreamNonBlocking));
         }
     }
 
@@ -565,6 +537,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         CREATE_TRY(hipMalloc(&s.out32_dev, (int64_t)c.max_batch * D * 4));
         CREATE_TRY(hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
     }
     CREATE_TRY(hipStreamSynchronize(st));
 #undef CREATE_TRY
@@ -651,14 +624,70 @@ extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* fra
     }
     HIP_TRY(hipMemcpyAsync(s.in_dev, s.in_host, (int64_t)n * plane, hipMemcpyHostToDevice, h->copy));
     HIP_TRY(hipEventRecord(s.ev_copied, h->copy));
-    HIP_TRY(hipStreamWaitEvent(h->compute, s.ev_copied, 0));
-    rc = forward_u8(h, s.in_dev, n, height, width, plane, width, 1, s.out32_dev, s.out16_dev, h->compute, -1, -1);
+    const int lane = (int)(h->submit_count++ % (uint64_t)h->n_lanes);
+    hipStream_t ls = h->lanes[lane].stream;
+    HIP_TRY(hipStreamWaitEvent(ls, s.ev_copied, 0));
+    use_lane(h, lane);
+    rc = forward_u8(h, s.in_dev, n, height, width, plane, width, 1, s.out32_dev, s.out16_dev, ls, -1, -1);
+    use_lane(h, 0);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(s.out16_host, s.out16_dev, (int64_t)n * h->D * 2, hipMemcpyDeviceToHost, h->compute));
-    HIP_TRY(hipMemcpyAsync(s.out32_host, s.out32_dev, (int64_t)n * h->D * 4, hipMemcpyDeviceToHost, h->compute));
-    HIP_TRY(hipEventRecord(s.ev_done, h->compute));
+    HIP_TRY(hipMemcpyAsync(s.out16_host, s.out16_dev, (int64_t)n * h->D * 2, hipMemcpyDeviceToHost, ls));
+    HIP_TRY(hipMemcpyAsync(s.out32_host, s.out32_dev, (int64_t)n * h->D * 4, hipMemcpyDeviceToHost, ls));
+    HIP_TRY(hipEventRecord(s.ev_done, ls));
     s.n = n;
     s.busy = true;
+    s.dev_mode = false;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_submit_u8(cbas_enc* h, int slot, const uint8_t* frames_dev, int n, int height, int width,
+                                  int64_t frame_stride, int64_t row_stride, int64_t pixel_stride, float* cls_f32_dev,
+                                  uint16_t* cls_f16_dev, void* after_stream) {
+    int rc = check_frame(h, n, height, width);
+    if (rc) return rc;
+    if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
+    if (!frames_dev) return cbas_fail(CBAS_EINVAL, "frames_dev is NULL");
+    if (!cls_f32_dev && !cls_f16_dev) return cbas_fail(CBAS_EINVAL, "no output requested");
+    Slot& s = h->slots[slot];
+    if (s.busy) return cbas_fail(CBAS_ESTATE, "slot %d is busy; call cbas_enc_wait_stream first", slot);
+    HIP_TRY(hipSetDevice(h->device));
+    const int lane = (int)(h->submit_count++ % (uint64_t)h->n_lanes);
+    hipStream_t ls = h->lanes[lane].stream;
+    HIP_TRY(hipEventRecord(s.ev_in, (hipStream_t)after_stream));      // the frames (and the output rows) are ready
+    HIP_TRY(hipStreamWaitEvent(ls, s.ev_in, 0));
+    use_lane(h, lane);
+    rc = forward_u8(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32_dev,
+                    (f16*)cls_f16_dev, ls, -1, -1);
+    use_lane(h, 0);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s.ev_done, ls));
+    s.n = n;
+    s.busy = true;
+    s.dev_mode = true;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_set_lanes(cbas_enc* h, int n_lanes) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    if (n_lanes < 1 || n_lanes > 2 || (n_lanes == 2 && !h->lanes[1].stream))
+        return cbas_fail(CBAS_EINVAL, "n_lanes=%d not available (handle was created with %s)", n_lanes,
+                         h->lanes[1].stream ? "2 lanes" : "CBAS_LANES=1");
+    for (const Slot& s : h->slots)
+        if (s.busy) return cbas_fail(CBAS_ESTATE, "cbas_enc_set_lanes with a batch in flight");
+    h->n_lanes = n_lanes;
+    h->submit_count = 0;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
+    Slot& s = h->slots[slot];
+    if (!s.busy) return cbas_fail(CBAS_ESTATE, "slot %d has no submitted work", slot);
+    if (!s.dev_mode) return cbas_fail(CBAS_ESTATE, "slot %d holds a host submission; use cbas_enc_wait", slot);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s.ev_done, 0));
+    s.busy = false;
     return CBAS_OK;
 }
 
@@ -667,6 +696,7 @@ extern "C" int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, floa
     if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
     Slot& s = h->slots[slot];
     if (!s.busy) return cbas_fail(CBAS_ESTATE, "slot %d has no submitted work", slot);
+    if (s.dev_mode) return cbas_fail(CBAS_ESTATE, "slot %d holds a device submission; use cbas_enc_wait_stream", slot);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventSynchronize(s.ev_done));
     if (cls_f16_host) memcpy(cls_f16_host, s.out16_host, (int64_t)s.n * h->D * 2);

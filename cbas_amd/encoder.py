@@ -173,6 +173,33 @@ class DinoEncoder:
         self._slot_n = getattr(self, "_slot_n", {})
         self._slot_n[slot] = n
 
+    def submit_dev(self, slot: int, frames: torch.Tensor, out16: Optional[torch.Tensor], out32: Optional[torch.Tensor] = None,
+                   channel: int = 1) -> None:
+        """Asynchronous encode of one device batch (<= max_batch frames, uint8 (n,H,W,3) or (n,H,W)) into the
+        given output rows, on one of the handle's two compute lanes, ordered after the current torch stream.
+        Call ``wait_stream(slot)`` before anything reads the outputs or overwrites the frames."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous()
+        if frames.dim() == 4:
+            n, H, W, Cn = frames.shape
+            strides, off = (H * W * Cn, W * Cn, Cn), channel
+        else:
+            n, H, W = frames.shape
+            strides, off = (H * W, W, 1), 0
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.cbas_enc_submit_u8(self._h, slot, frames.data_ptr() + off, n, H, W, *strides,
+                                                out32.data_ptr() if out32 is not None else None,
+                                                out16.data_ptr() if out16 is not None else None, stream),
+                   "cbas_enc_submit_u8")
+
+    def set_lanes(self, n: int) -> None:
+        """1 or 2 compute lanes for the asynchronous forms (default 2: two batches in flight)."""
+        _lib.check(self._lib.cbas_enc_set_lanes(self._h, int(n)), "cbas_enc_set_lanes")
+
+    def wait_stream(self, slot: int) -> None:
+        """The current torch stream waits for ``slot``'s batch (no host synchronisation); frees the slot."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.cbas_enc_wait_stream(self._h, slot, stream), "cbas_enc_wait_stream")
+
     def wait(self, slot: int, want_f32: bool = False):
         n = getattr(self, "_slot_n", {}).pop(slot, None)
         if n is None:

@@ -31,8 +31,15 @@ class ClipStream:
         self.reset()
 
     def reset(self) -> None:
+        self._drain()
         self.encoded = 0
         self.classified = 0
+
+    def _drain(self) -> None:
+        """Order the current stream after every batch still in flight on the encoder's compute lanes."""
+        for slot in list(getattr(self, "_busy", {})):
+            self.enc.wait_stream(slot)
+        self._busy = {}
 
     def push_u8(self, frames: torch.Tensor, channel: int = 1) -> None:
         """Encode one batch of uint8 frames resident in HBM ((n,H,W,3) or (n,H,W)) and classify every
@@ -55,13 +62,20 @@ class ClipStream:
         else:
             n, H, W = frames.shape
             strides, off = (H * W, W, 1), 0
-        stream = torch.cuda.current_stream(enc.device).cuda_stream
+        # asynchronous submissions on the encoder's two compute lanes: consecutive batches overlap
+        frames = frames.contiguous()
         for i in range(0, n, enc.max_batch):
             m = min(enc.max_batch, n - i)
-            _lib.check(enc._lib.cbas_enc_forward_u8(enc._h, frames[i:i + m].data_ptr() + off, m, H, W, *strides,
-                                                    None, out16[i:i + m].data_ptr(), stream), "cbas_enc_forward_u8")
+            slot = self._next_slot = (getattr(self, "_next_slot", -1) + 1) % _lib.ENC_SLOTS
+            if slot in self._busy:
+                enc.wait_stream(slot)
+                del self._busy[slot]
+            sub = frames[i:i + m]
+            enc.submit_dev(slot, sub, out16[i:i + m], None, channel)
+            self._busy[slot] = sub                      # keeps the frames alive until the slot is waited for
 
     def _classify(self, count: int) -> None:
+        self._drain()
         self.head.infer_range_into(self.cls16, self.encoded, self.classified, count, self.probs, self.temperature)
         self.classified += count
 
@@ -70,4 +84,5 @@ class ClipStream:
         (cls_f16 (N,D), probs (N,C)) views on the device."""
         if self.encoded > self.classified:
             self._classify(self.encoded - self.classified)
+        self._drain()
         return self.cls16[:self.encoded], self.probs[:self.encoded]

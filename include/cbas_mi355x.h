@@ -49,7 +49,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   4
+#define CBAS_ABI_VERSION   5
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -112,6 +112,22 @@ int cbas_enc_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int heigh
 int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
                             int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride);
 int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, float* cls_f32_host);
+
+/* Asynchronous device-resident form (the chunk loop when the frames are already in HBM, and the live
+ * encode -> head stream): like cbas_enc_forward_u8, but the batch runs on one of the handle's two compute
+ * lanes (own workspace + stream; submissions alternate), ordered after everything queued so far on
+ * `after_stream`.  Two consecutive submissions are therefore in flight together: one batch's partial tile
+ * rounds, LayerNorm and attention run under the other batch's GEMMs (+10 % throughput on MI355X, outputs
+ * bit-identical to the synchronous form).  cbas_enc_wait_stream makes `stream` wait for the slot's batch
+ * (no host block) and frees the slot; until then frames_dev must stay valid and the outputs untouched.
+ * The host-streamed form above alternates the same two lanes. */
+int cbas_enc_submit_u8(cbas_enc* h, int slot, const uint8_t* frames_dev, int n, int height, int width,
+                       int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                       float* cls_f32_dev, uint16_t* cls_f16_dev, void* after_stream);
+int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream);
+/* Use 1 or 2 compute lanes for the asynchronous forms (2 by default; 1 serialises the batches, e.g. to time
+ * kernels without another batch's kernels running beside them).  No batch may be in flight. */
+int cbas_enc_set_lanes(cbas_enc* h, int n_lanes);
 
 /* Bring-up/debug: run the forward pass only up to (layer, stage) and copy an internal buffer to
  * the host.  stage: 0 embeddings (x), then per layer 1 LN1(h16) 2 QKV(qkv16) 3 attention(h16)
