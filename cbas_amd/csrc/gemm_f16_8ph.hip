@@ -321,7 +321,8 @@ PPPlan pp_plan(int M, int N) {
         const double t = pp_makespan(n, pp_tile_cost(bm), 0, 0.0, cus);
         if (t < best_t - 1e-9) { best = {bm, 0}; best_t = t; }
     }
-    for (int mp = 1; mp * 256 < M; ++mp) {
+    static const bool no_tail = [] { const char* e = getenv("CBAS_PP_NO_TAIL"); return e && e[0] == '1'; }();   // experiments
+    for (int mp = 1; mp * 256 < M && !no_tail; ++mp) {
         const int n_main = mp * tiles_n, n_tail = ((M - mp * 256 + 127) / 128) * tiles_n;
         const double t = pp_makespan(n_main, 1.0, n_tail, pp_tile_cost(128), cus);
         if (t < best_t - 0.02) { best = {256, mp}; best_t = t; }      // prefer a uniform grid on near-ties
