@@ -310,3 +310,41 @@ def test_encode_file_and_infer_file_dropins(golden_dir, tmp_path):
 def test_smoke_entry():
     import __graft_entry__ as G
     G.smoke()
+
+
+def test_async_lanes_match_synchronous_forward():
+    """cbas_enc_submit_u8 / wait_stream (two batches in flight on two compute lanes) give the synchronous
+    result bit for bit, for ragged batch sizes, in any slot order, with 1 or 2 lanes; slot misuse is an error."""
+    from cbas_amd import _lib as L
+    from cbas_amd.encoder import DinoEncoder
+    cfg = C.VIT_TINY
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=16, max_frame=(64, 64))
+    frames = torch.from_numpy(synth.cage_frames(11, 75, 64, 64)).cuda()
+    ref, _ = enc.encode_u8(frames, want_f32=False)
+    torch.cuda.synchronize()
+    sizes = [16, 5, 16, 1, 16, 16, 5]                     # 75 frames in ragged batches
+    for lanes in (2, 1, 2):
+        enc.set_lanes(lanes)
+        out = torch.zeros_like(ref)
+        busy, o = [], 0
+        for i, n in enumerate(sizes):
+            slot = i % L.ENC_SLOTS
+            if slot in busy:
+                enc.wait_stream(slot)
+                busy.remove(slot)
+            enc.submit_dev(slot, frames[o:o + n], out[o:o + n])
+            busy.append(slot)
+            o += n
+        with pytest.raises(RuntimeError, match="busy"):
+            enc.submit_dev(busy[-1], frames[:4], out[:4])
+        with pytest.raises(RuntimeError, match="slot"):       # host-style wait on a device submission
+            enc.wait(busy[-1])
+        with pytest.raises(RuntimeError, match="in flight"):
+            enc.set_lanes(1)
+        for slot in busy:
+            enc.wait_stream(slot)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), lanes
+        with pytest.raises(RuntimeError, match="no submitted work"):
+            enc.wait_stream(0)
+    enc.close()
