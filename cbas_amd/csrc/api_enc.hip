@@ -82,6 +82,10 @@ struct cbas_enc {
     Lane lanes[2] = {};
     int n_lanes = 1;
     uint64_t submit_count = 0;
+    // ordering between the synchronous calls (lane 0 workspace on the CALLER's stream) and asynchronous batches
+    // on lane 0's own stream, so that mixing the two forms on one handle never races on the workspace
+    hipEvent_t lane0_async_done = nullptr, sync_done = nullptr;
+    bool lane0_async_used = false, sync_used = false;
     // optional per-kernel-category timing (HIP events on the launch stream)
     bool prof_on = false;
     struct ProfRec { hipEvent_t a, b; int cat; double flops; };
@@ -349,6 +353,8 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
     if (h->lanes[0].x) { h->A_patch = h->lanes[0].A_patch; h->x = h->lanes[0].x; h->h16 = h->lanes[0].h16;
                          h->qkv16 = h->lanes[0].qkv16; h->u16 = h->lanes[0].u16; }
     if (h->lanes[1].stream) { (void)hipStreamSynchronize(h->lanes[1].stream); (void)hipStreamDestroy(h->lanes[1].stream); }
+    if (h->lane0_async_done) (void)hipEventDestroy(h->lane0_async_done);
+    if (h->sync_done) (void)hipEventDestroy(h->sync_done);
     {
         void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16};
         for (void* b : b1) if (b) (void)hipFree(b);
@@ -524,6 +530,8 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
             CREATE_TRY(hipMemsetAsync(L1.u16, 0, h->rows_cap * F * sizeof(f16), st));
             CREATE_TRY(hipStreamCreateWithFlags(&L1.stream, hipStreamNonBlocking));
         }
+        CREATE_TRY(hipEventCreateWithFlags(&h->lane0_async_done, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&h->sync_done, hipEventDisableTiming));
     }
 
     // host-streaming slots
@@ -545,13 +553,37 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     return CBAS_OK;
 }
 
+// a synchronous call is about to use lane 0's workspace on stream st
+static int sync_enter(cbas_enc* h, hipStream_t st) {
+    if (h->lane0_async_used) HIP_TRY(hipStreamWaitEvent(st, h->lane0_async_done, 0));
+    return CBAS_OK;
+}
+static int sync_leave(cbas_enc* h, hipStream_t st) {
+    HIP_TRY(hipEventRecord(h->sync_done, st));
+    h->sync_used = true;
+    return CBAS_OK;
+}
+// an asynchronous batch is about to use `lane` on its own stream ls / has been queued there
+static int async_enter(cbas_enc* h, int lane, hipStream_t ls) {
+    if (lane == 0 && h->sync_used) HIP_TRY(hipStreamWaitEvent(ls, h->sync_done, 0));
+    return CBAS_OK;
+}
+static int async_leave(cbas_enc* h, int lane, hipStream_t ls) {
+    if (lane == 0) { HIP_TRY(hipEventRecord(h->lane0_async_done, ls)); h->lane0_async_used = true; }
+    return CBAS_OK;
+}
+
 extern "C" int cbas_enc_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
                                    int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
                                    float* cls_f32_dev, uint16_t* cls_f16_dev, void* stream) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
     hipStream_t st = (hipStream_t)stream;
-    return forward_u8(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32_dev,
-                      (f16*)cls_f16_dev, st, -1, -1);
+    int rc = sync_enter(h, st);
+    if (rc) return rc;
+    rc = forward_u8(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32_dev,
+                    (f16*)cls_f16_dev, st, -1, -1);
+    if (rc) return rc;
+    return sync_leave(h, st);
 }
 
 extern "C" int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int height, int width,
@@ -563,8 +595,12 @@ extern "C" int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int 
     hipStream_t st = (hipStream_t)stream;
     const int ps = h->cfg.patch_size;
     const int T = (height / ps) * (width / ps) + h->NP;
+    rc = sync_enter(h, st);
+    if (rc) return rc;
     LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, ps, st));
-    return run_blocks(h, n, height, width, 512, 1.0f, cls_f32_dev, (f16*)cls_f16_dev, st, -1, -1);
+    rc = run_blocks(h, n, height, width, 512, 1.0f, cls_f32_dev, (f16*)cls_f16_dev, st, -1, -1);
+    if (rc) return rc;
+    return sync_leave(h, st);
 }
 
 extern "C" int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
@@ -627,9 +663,13 @@ extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* fra
     const int lane = (int)(h->submit_count++ % (uint64_t)h->n_lanes);
     hipStream_t ls = h->lanes[lane].stream;
     HIP_TRY(hipStreamWaitEvent(ls, s.ev_copied, 0));
+    rc = async_enter(h, lane, ls);
+    if (rc) return rc;
     use_lane(h, lane);
     rc = forward_u8(h, s.in_dev, n, height, width, plane, width, 1, s.out32_dev, s.out16_dev, ls, -1, -1);
     use_lane(h, 0);
+    if (rc) return rc;
+    rc = async_leave(h, lane, ls);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(s.out16_host, s.out16_dev, (int64_t)n * h->D * 2, hipMemcpyDeviceToHost, ls));
     HIP_TRY(hipMemcpyAsync(s.out32_host, s.out32_dev, (int64_t)n * h->D * 4, hipMemcpyDeviceToHost, ls));
@@ -655,10 +695,14 @@ extern "C" int cbas_enc_submit_u8(cbas_enc* h, int slot, const uint8_t* frames_d
     hipStream_t ls = h->lanes[lane].stream;
     HIP_TRY(hipEventRecord(s.ev_in, (hipStream_t)after_stream));      // the frames (and the output rows) are ready
     HIP_TRY(hipStreamWaitEvent(ls, s.ev_in, 0));
+    rc = async_enter(h, lane, ls);
+    if (rc) return rc;
     use_lane(h, lane);
     rc = forward_u8(h, frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, cls_f32_dev,
                     (f16*)cls_f16_dev, ls, -1, -1);
     use_lane(h, 0);
+    if (rc) return rc;
+    rc = async_leave(h, lane, ls);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.ev_done, ls));
     s.n = n;

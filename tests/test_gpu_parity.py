@@ -348,3 +348,27 @@ def test_async_lanes_match_synchronous_forward():
         with pytest.raises(RuntimeError, match="no submitted work"):
             enc.wait_stream(0)
     enc.close()
+
+
+def test_mixing_sync_and_async_calls_on_one_handle():
+    """A synchronous forward issued while asynchronous batches are queued on lane 0 (and the reverse) is ordered
+    by the library: both forms use lane 0's workspace, neither corrupts the other."""
+    from cbas_amd.encoder import DinoEncoder
+    cfg = C.VIT_TINY
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=16, max_frame=(64, 64))
+    frames = torch.from_numpy(synth.cage_frames(13, 64, 64, 64)).cuda()
+    ref, _ = enc.encode_u8(frames, want_f32=False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        out = torch.zeros_like(ref)
+        enc.submit_dev(0, frames[0:16], out[0:16])            # lane 0
+        enc.submit_dev(1, frames[16:32], out[16:32])          # lane 1
+        with torch.cuda.stream(side):                         # synchronous forward on an unrelated stream
+            mid, _ = enc.encode_u8(frames[32:48], want_f32=False)
+        enc.submit_dev(2, frames[48:64], out[48:64])          # lane 0 again, after the synchronous call
+        for s in (0, 1, 2):
+            enc.wait_stream(s)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0:32], ref[0:32]) and torch.equal(out[48:64], ref[48:64]) and torch.equal(mid, ref[32:48]), rep
+    enc.close()
