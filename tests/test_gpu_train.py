@@ -180,3 +180,23 @@ def test_train_lstm_model_shim_runs_the_reference_loop():
     logits, latent = model(torch.from_numpy(x[:8]).cuda())
     assert logits.shape == (8, 4) and latent.shape == (8, 128)
     model.close()
+
+
+@pytest.mark.parametrize("I,Cn,T,h,nl,B", [(384, 4, 15, 64, 1, 20), (768, 12, 41, 128, 2, 9)])
+def test_other_shapes_against_oracle(I, Cn, T, h, nl, B):
+    """ViT-S width / short windows / 12 classes / long windows with a stacked h=128 LSTM: gradients vs float64 autograd."""
+    from oracle import head_train_oracle as HT
+    hcfg = C.HeadConfig(in_features=I, out_features=Cn, seq_len=T, lstm_hidden_size=h, lstm_layers=nl)
+    hw = W.synth_head_weights(hcfg, 99)
+    x, y = synth.train_windows(17, B, I, Cn, T)
+    tr = make_trainer(hcfg, hw, lr=1e-3, weight_decay=1e-2, dropout=True, seed=5)
+    loss, ce, cov = tr.step(torch.from_numpy(x), torch.from_numpy(y), update=False)
+    grads = tr.grads()
+    tr.close()
+    masks = HT.make_masks(5, 0, B, T, 128, 256)
+    rl, rce, rcov, _, _, rg = HT.loss_and_grads(x, y, hw, T, None, 0.0, masks, dtype=torch.float64)
+    assert abs(loss - rl) < 3e-5 * abs(rl), (loss, rl)
+    for name in hw:
+        scale = max(np.abs(rg[name]).max(), 1e-6)
+        floor = 5e-6 if name == "attention_head.bias" else 2e-7
+        assert np.abs(grads[name] - rg[name]).max() <= 4e-4 * scale + floor, (name, float(np.abs(grads[name] - rg[name]).max()), float(scale))
