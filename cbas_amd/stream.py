@@ -34,11 +34,14 @@ class ClipStream:
         self._drain()
         self.encoded = 0
         self.classified = 0
+        self.landed = 0          # rows whose batches the current stream is already ordered after
 
     def _drain(self) -> None:
         """Order the current stream after every batch still in flight on the encoder's compute lanes."""
-        for slot in list(getattr(self, "_busy", {})):
+        busy = getattr(self, "_busy", {})
+        for slot in sorted(busy, key=lambda s: busy[s][1]):          # submission order
             self.enc.wait_stream(slot)
+            self.landed += busy[slot][2]
         self._busy = {}
 
     def push_u8(self, frames: torch.Tensor, channel: int = 1) -> None:
@@ -49,9 +52,12 @@ class ClipStream:
             raise RuntimeError(f"ClipStream capacity {self.capacity} exceeded")
         self._encode_into(frames, channel, self.cls16[self.encoded:self.encoded + n])
         self.encoded += n
-        ready = self.encoded - self.half - self.classified          # frames with full right context
+        # The head only consumes rows the current stream is ALREADY ordered after (batches whose slot has been
+        # recycled): classifying never waits for the batches in flight, so the encoder lanes are not drained
+        # in the middle of a clip.  It therefore trails the encoder by up to ENC_SLOTS batches + the half window.
+        ready = self.landed - self.half - self.classified            # frames with full right context
         if ready >= self.classify_every:
-            self._classify(ready)
+            self._classify(ready, self.landed)
 
     def _encode_into(self, frames: torch.Tensor, channel: int, out16: torch.Tensor) -> None:
         from . import _lib
@@ -68,21 +74,22 @@ class ClipStream:
             m = min(enc.max_batch, n - i)
             slot = self._next_slot = (getattr(self, "_next_slot", -1) + 1) % _lib.ENC_SLOTS
             if slot in self._busy:
-                enc.wait_stream(slot)
-                del self._busy[slot]
+                enc.wait_stream(slot)                   # batches are recycled in submission order
+                self.landed += self._busy.pop(slot)[2]
             sub = frames[i:i + m]
             enc.submit_dev(slot, sub, out16[i:i + m], None, channel)
-            self._busy[slot] = sub                      # keeps the frames alive until the slot is waited for
+            self._seq = getattr(self, "_seq", 0) + 1
+            self._busy[slot] = (sub, self._seq, m)      # keeps the frames alive until the slot is waited for
 
-    def _classify(self, count: int) -> None:
-        self._drain()
-        self.head.infer_range_into(self.cls16, self.encoded, self.classified, count, self.probs, self.temperature)
+    def _classify(self, count: int, n_rows: int) -> None:
+        """Classify frames [classified, classified + count) of the first ``n_rows`` rows (all landed)."""
+        self.head.infer_range_into(self.cls16, n_rows, self.classified, count, self.probs, self.temperature)
         self.classified += count
 
     def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Classify the tail (the clip's right edge replicates its last row) and return
         (cls_f16 (N,D), probs (N,C)) views on the device."""
-        if self.encoded > self.classified:
-            self._classify(self.encoded - self.classified)
         self._drain()
+        if self.encoded > self.classified:
+            self._classify(self.encoded - self.classified, self.encoded)
         return self.cls16[:self.encoded], self.probs[:self.encoded]
