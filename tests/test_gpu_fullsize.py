@@ -103,3 +103,63 @@ def test_sampled_oracle_agreement(clip_run):
     ref_p = H.softmax_T(logits, 1.0)
     n_mis, _ = assert_labels_match(clip_run["probs"][sel].cpu().numpy(), ref_p, 1e-4)
     assert n_mis == 0
+
+
+def test_handles_are_usable_from_concurrent_threads():
+    """EncodeThread and ClassificationThread are distinct OS threads in CBAS (workthreads.py:1256-1267) and a
+    TrainingThread may run too: an encoder, a head and a trainer driven from three Python threads at once give
+    the results of running them one after the other."""
+    import threading
+    from cbas_amd.encoder import DinoEncoder
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from cbas_amd.train import HeadTrainer
+    from cbas_amd import synth
+    cfg = C.NAMED_VIT["vits16"]
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=32, max_frame=(224, 224))
+    hcfg = C.HeadConfig()
+    hw = W.synth_head_weights(hcfg, 4321)
+    head = ClassifierLSTMDeltas(768, 9)
+    head.load_state_dict(hw)
+    head.to("cuda")
+    frames = torch.from_numpy(synth.cage_frames(2, 96, 224, 224)).cuda()
+    cls = torch.from_numpy(synth.cls_walk(4, 3000, 768)).cuda()
+    x, y = synth.train_windows(6, 128, 768, 9, 31)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+    def enc_job(out):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(6):
+                out.append(enc.encode_u8(frames, want_f32=False)[0])
+            s.synchronize()
+
+    def head_job(out):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(6):
+                out.append(head.infer_clip(cls))
+            s.synchronize()
+
+    def train_job(out):
+        tr = HeadTrainer(hcfg, hw, "cuda", lr=1e-3, max_batch=128, seed=3)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            out.extend(tr.step(xt, yt)[0] for _ in range(6))
+        out.append(tr.weights())
+        tr.close()
+
+    seq = ([], [], [])
+    enc_job(seq[0]); head_job(seq[1]); train_job(seq[2])
+    par = ([], [], [])
+    threads = [threading.Thread(target=f, args=(o,)) for f, o in ((enc_job, par[0]), (head_job, par[1]), (train_job, par[2]))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+        assert not t.is_alive()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(seq[0], par[0])) and all(torch.equal(a, seq[0][0]) for a in par[0])
+    assert all(torch.equal(a, b) for a, b in zip(seq[1], par[1]))
+    assert seq[2][:6] == par[2][:6] and all(np.array_equal(seq[2][6][k], par[2][6][k]) for k in seq[2][6])
+    enc.close()
+    head.close()
