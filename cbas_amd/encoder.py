@@ -88,10 +88,31 @@ class DinoEncoder:
         need = self._lib.cbas_enc_weights_count(C.byref(self._cfg_c))
         if need != blob.shape[0]:
             raise RuntimeError(f"weight blob has {blob.shape[0]} floats, library expects {need}")
+        self._blob = blob                 # kept so that the handle can be rebuilt for larger frames
+        self._h = None
+        self._create()
+
+    def _create(self) -> None:
         h = C.c_void_p()
-        _lib.check(self._lib.cbas_enc_create(C.byref(self._cfg_c), blob.ctypes.data, blob.shape[0], self._dev,
+        _lib.check(self._lib.cbas_enc_create(C.byref(self._cfg_c), self._blob.ctypes.data, self._blob.shape[0], self._dev,
                                              C.byref(h)), "cbas_enc_create")
         self._h = h
+
+    def _fit_frame(self, H: int, W: int) -> None:
+        """The reference takes any frame size; the workspace here is sized at create.  Frames larger than
+        ``max_frame`` rebuild the handle once with a workspace that fits them (weights are re-uploaded)."""
+        if H <= self.max_frame[0] and W <= self.max_frame[1]:
+            return
+        if getattr(self, "_slot_n", None):
+            raise RuntimeError("frame size grew while batches are in flight; wait for them first")
+        new = (max(H, self.max_frame[0]), max(W, self.max_frame[1]))
+        print(f"cbas_amd: frames of {H}x{W} exceed the encoder workspace ({self.max_frame[0]}x{self.max_frame[1]}); "
+              f"rebuilding it for {new[0]}x{new[1]}")
+        torch.cuda.synchronize(self.device)
+        self.close()
+        self.max_frame = new
+        self._cfg_c.max_height, self._cfg_c.max_width = new
+        self._create()
 
     # -- nn.Module-like surface used by the reference ------------------------------------------
     def eval(self):
@@ -123,6 +144,7 @@ class DinoEncoder:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """backend/cbas.py:672-677: x (B,S,H,W) float32 in [0,1] -> (B,S,D) float32."""
         B, S, H, W = x.shape
+        self._fit_frame(H, W)
         x = x.to(self.device, dtype=torch.float32).contiguous().reshape(B * S, H, W)
         out = torch.empty((B * S, self.config.hidden_size), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -147,6 +169,7 @@ class DinoEncoder:
             n, H, W = frames.shape
             strides = (H * W, W, 1)
             base_off = 0
+        self._fit_frame(H, W)
         D = self.config.hidden_size
         out16 = torch.empty((n, D), dtype=torch.float16, device=self.device)
         out32 = torch.empty((n, D), dtype=torch.float32, device=self.device) if want_f32 else None
@@ -168,6 +191,7 @@ class DinoEncoder:
         else:
             n, H, W = frames.shape
             strides, off = (H * W, W, 1), 0
+        self._fit_frame(H, W)
         _lib.check(self._lib.cbas_enc_submit_u8_host(self._h, slot, frames.ctypes.data + off, n, H, W, *strides),
                    "cbas_enc_submit_u8_host")
         self._slot_n = getattr(self, "_slot_n", {})
@@ -185,6 +209,9 @@ class DinoEncoder:
         else:
             n, H, W = frames.shape
             strides, off = (H * W, W, 1), 0
+        if H > self.max_frame[0] or W > self.max_frame[1]:
+            raise RuntimeError(f"frames of {H}x{W} exceed the encoder workspace {self.max_frame}; create the encoder with "
+                               "max_frame=(H, W) (the asynchronous form cannot rebuild the handle with batches in flight)")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.cbas_enc_submit_u8(self._h, slot, frames.data_ptr() + off, n, H, W, *strides,
                                                 out32.data_ptr() if out32 is not None else None,

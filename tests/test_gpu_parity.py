@@ -397,3 +397,24 @@ def test_massive_activation_channels_stay_within_tolerance():
     assert np.abs(tap).max() > 60.0                                    # the outliers are really there
     r = rel_rows(c32.cpu().numpy(), ref)
     assert r.max() < CLS_TOL, r.max()
+
+
+def test_encoder_workspace_grows_for_larger_frames(golden_dir):
+    """DinoEncoder takes any frame size, like the reference: a frame larger than max_frame rebuilds the handle."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.VIT_TINY
+    w = W.synth_encoder_weights(cfg, 1234)
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=4, max_frame=(64, 64))
+    small = synth.cage_frames(3, 2, 64, 64)
+    big = synth.cage_frames(3, 2, 96, 128)
+    a16, a32 = enc.encode_u8(torch.from_numpy(small).cuda())
+    b16, b32 = enc.encode_u8(torch.from_numpy(big).cuda())                 # 96x128 > 64x64: rebuild
+    assert enc.max_frame == (96, 128)
+    c16, c32 = enc.encode_u8(torch.from_numpy(small).cuda())               # small frames still work, same result
+    assert torch.equal(a32, c32)
+    ref = PO.encode_frames(big, w, cfg, batch=2)
+    assert rel_rows(b32.cpu().numpy(), ref).max() < CLS_TOL
+    enc.submit_host(0, big)
+    assert np.array_equal(enc.wait(0, want_f32=True)[1], b32.cpu().numpy())
+    enc.close()
