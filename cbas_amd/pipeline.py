@@ -130,6 +130,54 @@ def encode_file(encoder: DinoEncoder, path: str, progress_callback=None, reader=
             reader.close()
 
 
+class _WriterThread:
+    """Runs ``ClsWriter.append`` / ``flush`` on a background thread so that HDF5 I/O overlaps frame staging and
+    kernel submission (libhdf5 calls go through ctypes/h5py and release the GIL).  Order is preserved; the
+    first error is re-raised on the caller's thread at the next call or at ``close``."""
+
+    def __init__(self, writer):
+        import queue
+        import threading
+        self._w, self._q, self._err = writer, queue.Queue(maxsize=8), None
+        self._t = threading.Thread(target=self._run, name="cbas-h5-writer", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if self._err is not None:
+                continue                                  # drain after a failure
+            try:
+                if isinstance(item, str):
+                    self._w.flush()
+                else:
+                    self._w.append(item)
+            except BaseException as e:  # noqa: BLE001
+                self._err = e
+
+    def _check(self):
+        if self._err is not None:
+            raise self._err
+
+    def append(self, rows):
+        self._check()
+        self._q.put(rows)
+
+    def flush(self):
+        self._check()
+        self._q.put("flush")
+
+    def stop(self):
+        """Finish queued work and join the thread (never raises; call ``check`` afterwards)."""
+        if self._t.is_alive():
+            self._q.put(None)
+            self._t.join()
+
+    check = _check
+
+
 def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callback) -> Optional[str]:
     video_len = len(reader)
     if video_len == 0:
@@ -145,40 +193,13 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
         stamp = _current_stamp()
         if stamp:
             attrs = {"encoder_model_identifier": stamp, "schema_version": SCHEMA_VERSION}
-        with h5io.ClsWriter(tmp_file_path, D, attrs) as w:
-            inflight: deque = deque()        # (slot, n_frames) in submission order
-            free = list(range(nslots))
-            keep: List[np.ndarray] = []      # keep chunk arrays alive until their sub-batches are staged
-
-            def drain_one():
-                slot, _n = inflight.popleft()
-                rows, _ = encoder.wait(slot)
-                w.append(rows)
-                free.append(slot)
-
-            for i in range(0, video_len, CHUNK_SIZE):
-                end_index = min(i + CHUNK_SIZE, video_len)
-                frames_np = reader.get_batch(range(i, end_index))     # (n,H,W,3) uint8, host
-                if progress_callback:
-                    progress_callback((end_index / video_len) * 100)
-                frames_np = np.ascontiguousarray(frames_np)
-                keep = [frames_np]
-                for j in range(0, frames_np.shape[0], encoder.max_batch):
-                    if not free:
-                        drain_one()
-                    slot = free.pop(0)
-                    sub = frames_np[j:j + encoder.max_batch]
-                    encoder.submit_host(slot, sub, channel=1)          # green channel, cbas.py:431
-                    inflight.append((slot, sub.shape[0]))
-                # the reference flushes once per 512-frame chunk (cbas.py:440); results of this chunk
-                # may still be in flight, so flush what has landed and keep streaming
-                while len(inflight) > nslots - 1:
-                    drain_one()
-                w.flush()
-            while inflight:
-                drain_one()
-            w.flush()
-            del keep
+        with h5io.ClsWriter(tmp_file_path, D, attrs) as w_sync:
+            w = _WriterThread(w_sync)
+            try:
+                _stream_chunks(encoder, reader, video_len, progress_callback, w, nslots)
+            finally:
+                w.stop()                     # the file is closed only after the writer thread has finished
+            w.check()
         os.replace(tmp_file_path, out_file_path)
         print(f"Successfully encoded {os.path.basename(path)} to {os.path.basename(out_file_path)}")
         return out_file_path
@@ -199,6 +220,43 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
                 except OSError:
                     pass
         raise e
+
+
+def _stream_chunks(encoder: DinoEncoder, reader, video_len: int, progress_callback, w, nslots: int) -> None:
+    """The chunk loop of encode_file (cbas.py:423-440) on the asynchronous slots."""
+    inflight: deque = deque()        # (slot, n_frames) in submission order
+    free = list(range(nslots))
+    keep: List[np.ndarray] = []      # keep chunk arrays alive until their sub-batches are staged
+
+    def drain_one():
+        slot, _n = inflight.popleft()
+        rows, _ = encoder.wait(slot)
+        w.append(rows)
+        free.append(slot)
+
+    for i in range(0, video_len, CHUNK_SIZE):
+        end_index = min(i + CHUNK_SIZE, video_len)
+        frames_np = reader.get_batch(range(i, end_index))     # (n,H,W,3) uint8, host
+        if progress_callback:
+            progress_callback((end_index / video_len) * 100)
+        frames_np = np.ascontiguousarray(frames_np)
+        keep = [frames_np]
+        for j in range(0, frames_np.shape[0], encoder.max_batch):
+            if not free:
+                drain_one()
+            slot = free.pop(0)
+            sub = frames_np[j:j + encoder.max_batch]
+            encoder.submit_host(slot, sub, channel=1)          # green channel, cbas.py:431
+            inflight.append((slot, sub.shape[0]))
+        # the reference flushes once per 512-frame chunk (cbas.py:440); results of this chunk
+        # may still be in flight, so flush what has landed and keep streaming
+        while len(inflight) > nslots - 1:
+            drain_one()
+        w.flush()
+    while inflight:
+        drain_one()
+    w.flush()
+    del keep
 
 
 # ------------------------------------------------------------------------------------------------
