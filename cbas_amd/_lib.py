@@ -50,6 +50,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "cbas_enc_wait_stream": (c_int, [c_void_p, c_int, c_void_p]),
     "cbas_enc_set_lanes": (c_int, [c_void_p, c_int]),
+    "cbas_enc_set_prune_last_layer": (c_int, [c_void_p, c_int]),
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int, c_int]),
     "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
@@ -77,6 +78,7 @@ SIGNATURES = {
 }
 
 ENC_SLOTS = 3
+EXPECTED_ABI = 6          # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
 PROF_CATS = ["patch_gemm", "layernorm", "qkv_gemm", "attention", "oproj_gemm", "up_gemm", "down_gemm", "other"]
 
 
@@ -98,11 +100,24 @@ def load(build_if_missing: bool = True):
             if not build_if_missing:
                 raise RuntimeError(f"{path} is missing; run `python -m cbas_amd.build`")
             _build.build_library()
+        elif _build._stale():
+            # sources newer than the binary: rebuild when asked to (CBAS_AUTOBUILD=1), otherwise say so -
+            # a silent stale binary is how an edited kernel "does nothing"
+            if os.environ.get("CBAS_AUTOBUILD") == "1":
+                _build.build_library()
+            else:
+                import sys
+                print(f"cbas_amd: {path} is older than its sources; run `python -m cbas_amd.build` "
+                      "(or set CBAS_AUTOBUILD=1)", file=sys.stderr)
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        abi = lib.cbas_abi_version()
+        if abi != EXPECTED_ABI:          # struct layouts below would not match: fail before any config is passed
+            raise RuntimeError(f"{path} implements ABI v{abi}, these bindings are for v{EXPECTED_ABI}; rebuild with "
+                               "`python -m cbas_amd.build --force`")
         _lib = lib
         return lib
 

@@ -63,22 +63,33 @@ struct cbas_enc {
     float* prefix_dev = nullptr;        // (1+R, D): cls (+ its position embedding for DINOv2) | registers
     float* pos_tab = nullptr;           // DINOv2: (Pmax, D) position embedding interpolated to the current grid
     std::vector<float> pos_host;        // DINOv2: raw (1+G*G, D) table
-    // rope tables for the last resolution
+    // RoPE (DINOv3) / interpolated position-embedding (DINOv2) tables, one set per patch grid seen so far.  A new
+    // grid gets FRESH device buffers filled by a blocking copy, so no stream has to be drained when a queue mixes
+    // resolutions; rope_cos / rope_sin / pos_tab point at the set of the batch being queued (kernel arguments are
+    // captured at launch).  Only when POS_TABLES_MAX grids are cached is the oldest one recycled behind a device sync.
+    struct PosTable { int nh = 0, nw = 0; float *cos = nullptr, *sin = nullptr, *pos = nullptr; uint64_t last_use = 0; };
+    static constexpr int POS_TABLES_MAX = 8;
+    std::vector<PosTable> pos_tables;
+    uint64_t pos_clock = 0;
     float *rope_cos = nullptr, *rope_sin = nullptr;
-    int rope_nh = 0, rope_nw = 0, rope_cap = 0;
+    int rope_cap = 0;
     // workspaces
     int64_t rows_cap = 0, prow_cap = 0;
     f16 *A_patch = nullptr, *h16 = nullptr, *qkv16 = nullptr, *u16 = nullptr;
     float* x = nullptr;
+    // compact per-frame rows of the pruned last layer (only the CLS row is consumed: [tf]:540-541, cbas.py:677):
+    // cls16 = [q | ctx | LN2 | (pad)] x [max_batch][D] fp16, then GELU(up) [max_batch][F]
+    f16* cls16 = nullptr;
+    bool prune_last = true;
     int last_rows = 0;
     hipStream_t compute = nullptr, copy = nullptr;
     Slot slots[CBAS_ENC_SLOTS];
-    int64_t slot_pixels = 0;
+    int64_t slot_bytes = 0;             // pinned staging / device input bytes per slot: max_batch x H x W x 4 channels
     // Two batches in flight: the asynchronous entry points (cbas_enc_submit_u8 / ..._host) alternate two
     // compute lanes, each a full workspace + its own stream, so that one batch's partial tile rounds,
     // LayerNorm and attention run under the other batch's GEMMs (+10 % measured; outputs bit-identical).
     // lane 0 = the buffers above on `compute`; the synchronous cbas_enc_forward_* always use lane 0.
-    struct Lane { f16 *A_patch, *h16, *qkv16, *u16; float* x; hipStream_t stream; };
+    struct Lane { f16 *A_patch, *h16, *qkv16, *u16, *cls16; float* x; hipStream_t stream; };
     Lane lanes[2] = {};
     int n_lanes = 1;
     uint64_t submit_count = 0;
@@ -130,11 +141,43 @@ static std::vector<float> aa_bicubic_matrix(int in_size, int out_size) {
     return W;
 }
 
-// DINOv2: position embedding of the patch tokens for an nh x nw grid ([v2] interpolate_pos_encoding :93-145)
-int ensure_pos_embed(cbas_enc* h, int nh, int nw, hipStream_t stream) {
-    if (h->rope_nh == nh && h->rope_nw == nw) return CBAS_OK;
-    const int P = nh * nw, G = h->cfg.pos_embed_grid, D = h->D;
+// Find or create the table set of an nh x nw patch grid and point the handle at it.
+int acquire_pos_table(cbas_enc* h, int nh, int nw, cbas_enc::PosTable** out) {
+    const int P = nh * nw;
     if (P > h->rope_cap) return cbas_fail(CBAS_EINVAL, "frame has %d patches, workspace holds %d", P, h->rope_cap);
+    *out = nullptr;
+    for (auto& t : h->pos_tables)
+        if (t.nh == nh && t.nw == nw) { t.last_use = ++h->pos_clock; *out = &t; return CBAS_OK; }
+    cbas_enc::PosTable* t = nullptr;
+    if ((int)h->pos_tables.size() < cbas_enc::POS_TABLES_MAX) {
+        h->pos_tables.emplace_back();
+        t = &h->pos_tables.back();
+        const size_t Pmax = (size_t)h->rope_cap;
+        if (h->cfg.use_rope) {
+            HIP_TRY(hipMalloc(&t->cos, Pmax * 64 * sizeof(float)));
+            HIP_TRY(hipMalloc(&t->sin, Pmax * 64 * sizeof(float)));
+        } else {
+            HIP_TRY(hipMalloc(&t->pos, Pmax * h->D * sizeof(float)));
+        }
+    } else {                                   // recycle the least recently used set: its readers must have finished
+        t = &h->pos_tables[0];
+        for (auto& c : h->pos_tables) if (c.last_use < t->last_use) t = &c;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    t->nh = -1; t->nw = -1;                    // not valid until filled
+    t->last_use = ++h->pos_clock;
+    *out = t;
+    return 1;                                  // caller fills it
+}
+
+// DINOv2: position embedding of the patch tokens for an nh x nw grid ([v2] interpolate_pos_encoding :93-145)
+int ensure_pos_embed(cbas_enc* h, int nh, int nw) {
+    cbas_enc::PosTable* t = nullptr;
+    const int rc = acquire_pos_table(h, nh, nw, &t);
+    if (rc < 0) return rc;
+    h->pos_tab = t->pos;
+    if (rc == 0) return CBAS_OK;
+    const int P = nh * nw, G = h->cfg.pos_embed_grid, D = h->D;
     const float* src = h->pos_host.data() + D;               // skip the cls position
     std::vector<float> out((size_t)P * D);
     if (nh == G && nw == G) {
@@ -144,12 +187,12 @@ int ensure_pos_embed(cbas_enc* h, int nh, int nw, hipStream_t stream) {
         std::vector<float> tmp((size_t)G * nw * D, 0.f);     // width pass, then height pass (separable)
         for (int i = 0; i < G; ++i)
             for (int x = 0; x < nw; ++x) {
-                float* t = &tmp[((size_t)i * nw + x) * D];
+                float* tp = &tmp[((size_t)i * nw + x) * D];
                 for (int j = 0; j < G; ++j) {
                     const float w = Ww[(size_t)x * G + j];
                     if (w == 0.f) continue;
                     const float* sp = src + ((size_t)i * G + j) * D;
-                    for (int d = 0; d < D; ++d) t[d] += w * sp[d];
+                    for (int d = 0; d < D; ++d) tp[d] += w * sp[d];
                 }
             }
         std::fill(out.begin(), out.end(), 0.f);
@@ -159,24 +202,24 @@ int ensure_pos_embed(cbas_enc* h, int nh, int nw, hipStream_t stream) {
                 if (w == 0.f) continue;
                 for (int x = 0; x < nw; ++x) {
                     float* o = &out[((size_t)y * nw + x) * D];
-                    const float* t = &tmp[((size_t)i * nw + x) * D];
-                    for (int d = 0; d < D; ++d) o[d] += w * t[d];
+                    const float* tp = &tmp[((size_t)i * nw + x) * D];
+                    for (int d = 0; d < D; ++d) o[d] += w * tp[d];
                 }
             }
     }
-    (void)stream;
-    HIP_TRY(hipDeviceSynchronize());       // first use of a resolution: the other lane may still read the old table
-    HIP_TRY(hipMemcpy(h->pos_tab, out.data(), out.size() * 4, hipMemcpyHostToDevice));
-    h->rope_nh = nh;
-    h->rope_nw = nw;
+    HIP_TRY(hipMemcpy(t->pos, out.data(), out.size() * 4, hipMemcpyHostToDevice));   // blocking; nothing reads t yet
+    t->nh = nh; t->nw = nw;
     return CBAS_OK;
 }
 
-int ensure_rope(cbas_enc* h, int nh, int nw, hipStream_t stream) {
-    if (!h->cfg.use_rope) return ensure_pos_embed(h, nh, nw, stream);
-    if (h->rope_nh == nh && h->rope_nw == nw) return CBAS_OK;
+int ensure_rope(cbas_enc* h, int nh, int nw) {
+    if (!h->cfg.use_rope) return ensure_pos_embed(h, nh, nw);
+    cbas_enc::PosTable* t = nullptr;
+    const int rc = acquire_pos_table(h, nh, nw, &t);
+    if (rc < 0) return rc;
+    h->rope_cos = t->cos; h->rope_sin = t->sin;
+    if (rc == 0) return CBAS_OK;
     const int P = nh * nw;
-    if (P > h->rope_cap) return cbas_fail(CBAS_EINVAL, "frame has %d patches, workspace holds %d", P, h->rope_cap);
     // [tf]:96-121 patch-centre coordinates, :153-200 angles; float32 throughout like the reference
     std::vector<float> c((size_t)P * 64), s((size_t)P * 64);
     float inv_freq[16];
@@ -195,13 +238,9 @@ int ensure_rope(cbas_enc* h, int nh, int nw, hipStream_t stream) {
                 sr[d] = sr[d + 32] = sinf(ang);
             }
         }
-    // synchronous copies (first use of a resolution only); the source vectors die at return
-    (void)stream;
-    HIP_TRY(hipDeviceSynchronize());       // first use of a resolution: the other lane may still read the old table
-    HIP_TRY(hipMemcpy(h->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
-    h->rope_nh = nh;
-    h->rope_nw = nw;
+    HIP_TRY(hipMemcpy(t->cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));       // blocking; nothing reads t yet
+    HIP_TRY(hipMemcpy(t->sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    t->nh = nh; t->nw = nw;
     return CBAS_OK;
 }
 
@@ -235,6 +274,47 @@ struct ProfScope {
 };
 #define PROF(cat, flops) ProfScope _prof_scope_##cat(h, st, cat, flops)
 
+
+// Last transformer layer when only the CLS rows are consumed.  K and V are still projected for every row
+// (the CLS query attends to all tokens); the query, attention, o_proj, LayerNorm 2 and the MLP run on the n CLS
+// rows, read and written in place in the residual stream with a row stride of T*D.
+int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t st) {
+    const int D = h->D, F = h->F, M = n * T, M_pad = (int)round_up(M, 128);
+    const int64_t cap = round_up(h->cfg.max_batch, 128);
+    f16* qc = h->cls16;                     // [n][D] CLS queries (bias added, scaled by 1/8; no RoPE on prefix rows)
+    f16* cc = qc + cap * D;                 // [n][D] attention context of the CLS rows
+    f16* hc = cc + cap * D;                 // [n][D] LayerNorm 2 of the CLS rows
+    f16* uc = hc + cap * D;                 // [n][F] GELU(up_proj)
+    const bool split = h->cfg.precision == 1;
+    { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+    GemmParams kv{};                        // k | v sections of the fused QKV weight, all rows
+    kv.A = h->h16; kv.W = w.wqkv + (size_t)D * D; kv.W_lo = split ? w.wqkv_lo + (size_t)D * D : nullptr;
+    kv.M = M; kv.M_pad = M_pad; kv.N = 2 * D; kv.K = D; kv.bias = w.qkv_b + D; kv.out_f16 = h->qkv16 + D; kv.ldo = 3 * D;
+    kv.tokens_per_frame = T; kv.n_prefix = h->NP; kv.D = D; kv.sec0 = 1;
+    kv.rope_cos = h->cfg.use_rope ? h->rope_cos : nullptr; kv.rope_sin = h->cfg.use_rope ? h->rope_sin : nullptr;
+    { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, kv, st)); }
+    GemmParams q{};                         // q section, CLS rows only (row b*T of h16)
+    q.A = h->h16; q.lda = T * D; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr;
+    q.M = n; q.M_pad = n; q.N = D; q.K = D; q.bias = w.qkv_b; q.out_f16 = qc; q.ldo = D;
+    q.tokens_per_frame = 1; q.n_prefix = 1; q.D = D; q.sec0 = 0;      // every row is token 0: no RoPE
+    { PROF(CBAS_PROF_QKV, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
+    { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * D); LAUNCH_TRY(launch_attention(h->qkv16, qc, cc, n, T, D, h->NH, st)); }
+    GemmParams o{};
+    o.A = cc; o.W = w.wo; o.W_lo = split ? w.wo_lo : nullptr;
+    o.M = n; o.M_pad = n; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out_f32 = h->x; o.ldo = T * D;
+    { PROF(CBAS_PROF_OPROJ, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_RESID, o, st)); }
+    { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, (int64_t)T * D, w.ln2_w, w.ln2_b, hc, n, D, h->cfg.layer_norm_eps, st)); }
+    GemmParams u{};
+    u.A = hc; u.W = w.wup; u.W_lo = split ? w.wup_lo : nullptr;
+    u.M = n; u.M_pad = n; u.N = F; u.K = D; u.bias = w.up_b; u.out_f16 = uc; u.ldo = F;
+    { PROF(CBAS_PROF_UP, 2.0 * n * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_GELU, u, st)); }
+    GemmParams d{};
+    d.A = uc; d.W = w.wdown; d.W_lo = split ? w.wdown_lo : nullptr;
+    d.M = n; d.M_pad = n; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out_f32 = h->x; d.ldo = T * D;
+    { PROF(CBAS_PROF_DOWN, 2.0 * n * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_RESID, d, st)); }
+    return CBAS_OK;
+}
+
 // Everything after ingest: patch GEMM, L transformer blocks, final CLS norm.
 int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_scale, float* cls_f32,
                f16* cls_f16, hipStream_t st, int stop_layer, int stop_stage) {
@@ -243,7 +323,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     const int D = h->D, F = h->F;
     const int M = n * T, M_pad = (int)round_up(M, 128);
     h->last_rows = M;
-    int rc = ensure_rope(h, nh, nw, st);
+    int rc = ensure_rope(h, nh, nw);
     if (rc) return rc;
 
     GemmParams g{};
@@ -257,10 +337,18 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     { PROF(CBAS_PROF_PATCH, 2.0 * g.M * g.N * g.K); LAUNCH_TRY(launch_gemm(EPI_PATCH, g, st)); }
     if (stop_layer == 0 && stop_stage == 0) return CBAS_OK;
 
+    // The last layer feeds only the final norm of the CLS rows, so everything after its K/V projection is
+    // done for n rows instead of n*T (rows are independent: bit-identical CLS).  Debug taps run it in full.
+    const bool prune = h->prune_last && stop_layer < 0 && (cls_f32 || cls_f16);
     for (int l = 0; l < h->L; ++l) {
         const LayerW& w = h->layers[l];
         auto stop = [&](int stage) { return stop_layer == l && stop_stage == stage; };
-        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+        if (prune && l == h->L - 1) {
+            rc = run_last_layer_cls(h, w, n, T, st);
+            if (rc) return rc;
+            break;
+        }
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         if (stop(1)) return CBAS_OK;
 
         GemmParams q{};
@@ -271,7 +359,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
         { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
         if (stop(2)) return CBAS_OK;
 
-        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention(h->qkv16, h->h16, n, T, D, h->NH, st)); }
+        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention(h->qkv16, nullptr, h->h16, n, T, D, h->NH, st)); }
         if (stop(3)) return CBAS_OK;
 
         GemmParams o{};
@@ -280,7 +368,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
         { PROF(CBAS_PROF_OPROJ, 2.0 * M * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_RESID, o, st)); }
         if (stop(4)) return CBAS_OK;
 
-        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         if (stop(5)) return CBAS_OK;
 
         GemmParams u{};
@@ -315,7 +403,7 @@ int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, in
 // host-side switch is safe while the other lane's kernels are still running).
 void use_lane(cbas_enc* h, int l) {
     const cbas_enc::Lane& L = h->lanes[l];
-    h->A_patch = L.A_patch; h->x = L.x; h->h16 = L.h16; h->qkv16 = L.qkv16; h->u16 = L.u16;
+    h->A_patch = L.A_patch; h->x = L.x; h->h16 = L.h16; h->qkv16 = L.qkv16; h->u16 = L.u16; h->cls16 = L.cls16;
 }
 
 int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
@@ -350,17 +438,17 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
     }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    if (h->lanes[0].x) { h->A_patch = h->lanes[0].A_patch; h->x = h->lanes[0].x; h->h16 = h->lanes[0].h16;
-                         h->qkv16 = h->lanes[0].qkv16; h->u16 = h->lanes[0].u16; }
+    if (h->lanes[0].x) use_lane(h, 0);
     if (h->lanes[1].stream) { (void)hipStreamSynchronize(h->lanes[1].stream); (void)hipStreamDestroy(h->lanes[1].stream); }
     if (h->lane0_async_done) (void)hipEventDestroy(h->lane0_async_done);
     if (h->sync_done) (void)hipEventDestroy(h->sync_done);
     {
-        void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16};
+        void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16, h->lanes[1].cls16};
         for (void* b : b1) if (b) (void)hipFree(b);
     }
-    void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->rope_cos, h->rope_sin, h->prefix_dev, h->pos_tab,
-                    h->A_patch, h->h16, h->qkv16, h->u16, h->x};
+    for (auto& t : h->pos_tables) { if (t.cos) (void)hipFree(t.cos); if (t.sin) (void)hipFree(t.sin); if (t.pos) (void)hipFree(t.pos); }
+    void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->prefix_dev,
+                    h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->compute) (void)hipStreamDestroy(h->compute);
@@ -497,14 +585,15 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     h->rows_cap = round_up((int64_t)c.max_batch * Tmax, 128);
     h->prow_cap = round_up((int64_t)c.max_batch * Pmax, 128);
     h->rope_cap = (int)Pmax;
-    CREATE_TRY(hipMalloc(&h->rope_cos, Pmax * 64 * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->rope_sin, Pmax * 64 * sizeof(float)));
-    if (c.pos_embed_grid > 0) CREATE_TRY(hipMalloc(&h->pos_tab, Pmax * D * sizeof(float)));
+    h->pos_tables.reserve(cbas_enc::POS_TABLES_MAX);     // entries are handed out by pointer: never reallocate
     CREATE_TRY(hipMalloc(&h->A_patch, h->prow_cap * 512 * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->x, h->rows_cap * D * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->h16, h->rows_cap * D * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->qkv16, h->rows_cap * 3 * D * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->u16, h->rows_cap * F * sizeof(f16)));
+    const int64_t cls_elems = round_up(c.max_batch, 128) * (3 * D + F);
+    CREATE_TRY(hipMalloc(&h->cls16, cls_elems * sizeof(f16)));
+    CREATE_TRY(hipMemsetAsync(h->cls16, 0, cls_elems * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->x, 0, h->rows_cap * D * sizeof(float), st));
     CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * sizeof(f16), st));
@@ -515,7 +604,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         const char* e = getenv("CBAS_LANES");
         h->n_lanes = (e && atoi(e) == 1) ? 1 : 2;
         cbas_enc::Lane& L0 = h->lanes[0];
-        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16; L0.stream = h->compute;
+        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16; L0.cls16 = h->cls16; L0.stream = h->compute;
         if (h->n_lanes == 2) {
             cbas_enc::Lane& L1 = h->lanes[1];
             CREATE_TRY(hipMalloc(&L1.A_patch, h->prow_cap * 512 * sizeof(f16)));
@@ -523,6 +612,8 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
             CREATE_TRY(hipMalloc(&L1.h16, h->rows_cap * D * sizeof(f16)));
             CREATE_TRY(hipMalloc(&L1.qkv16, h->rows_cap * 3 * D * sizeof(f16)));
             CREATE_TRY(hipMalloc(&L1.u16, h->rows_cap * F * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.cls16, cls_elems * sizeof(f16)));
+            CREATE_TRY(hipMemsetAsync(L1.cls16, 0, cls_elems * sizeof(f16), st));
             CREATE_TRY(hipMemsetAsync(L1.A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
             CREATE_TRY(hipMemsetAsync(L1.x, 0, h->rows_cap * D * sizeof(float), st));
             CREATE_TRY(hipMemsetAsync(L1.h16, 0, h->rows_cap * D * sizeof(f16), st));
@@ -535,12 +626,12 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     }
 
     // host-streaming slots
-    h->slot_pixels = (int64_t)c.max_batch * c.max_height * c.max_width;
+    h->slot_bytes = (int64_t)c.max_batch * c.max_height * c.max_width * 4;
     for (Slot& s : h->slots) {
-        CREATE_TRY(hipHostMalloc(&s.in_host, h->slot_pixels, hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc(&s.in_host, h->slot_bytes, hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc(&s.out16_host, (int64_t)c.max_batch * D * 2, hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc(&s.out32_host, (int64_t)c.max_batch * D * 4, hipHostMallocDefault));
-        CREATE_TRY(hipMalloc(&s.in_dev, h->slot_pixels));
+        CREATE_TRY(hipMalloc(&s.in_dev, h->slot_bytes));
         CREATE_TRY(hipMalloc(&s.out16_dev, (int64_t)c.max_batch * D * 2));
         CREATE_TRY(hipMalloc(&s.out32_dev, (int64_t)c.max_batch * D * 4));
         CREATE_TRY(hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
@@ -556,6 +647,8 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
 // a synchronous call is about to use lane 0's workspace on stream st
 static int sync_enter(cbas_enc* h, hipStream_t st) {
     if (h->lane0_async_used) HIP_TRY(hipStreamWaitEvent(st, h->lane0_async_done, 0));
+    // two synchronous calls on DIFFERENT caller streams share lane 0's workspace too (free when st is the same stream)
+    if (h->sync_used) HIP_TRY(hipStreamWaitEvent(st, h->sync_done, 0));
     return CBAS_OK;
 }
 static int sync_leave(cbas_enc* h, hipStream_t st) {
@@ -641,15 +734,35 @@ extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* fra
     Slot& s = h->slots[slot];
     if (s.busy) return cbas_fail(CBAS_ESTATE, "slot %d is busy; call cbas_enc_wait first", slot);
     const int64_t plane = (int64_t)height * width;
-    if ((int64_t)n * plane > h->slot_pixels) return cbas_fail(CBAS_EINVAL, "chunk exceeds slot staging size");
+    if (frame_stride < 0 || row_stride < 0 || pixel_stride < 1) return cbas_fail(CBAS_EINVAL, "negative stride");
     HIP_TRY(hipSetDevice(h->device));
-    // gather the consumed channel into the pinned staging buffer (packed green planes)
-    for (int f = 0; f < n; ++f) {
-        const uint8_t* src = frames_host + (int64_t)f * frame_stride;
-        uint8_t* dst = s.in_host + (int64_t)f * plane;
-        if (pixel_stride == 1 && row_stride == width) {
-            memcpy(dst, src, plane);
-        } else {
+    // Bytes of the caller's layout are shipped AS THEY ARE (for decord's (n,H,W,3) RGB: 3 bytes per pixel, trivial on
+    // PCIe 5) and the consumed channel is picked by the ingest kernel through the strides, so the host does no
+    // per-pixel work.  `ext` = bytes from a frame's first consumed pixel to its last.
+    const int64_t ext = (int64_t)(height - 1) * row_stride + (int64_t)(width - 1) * pixel_stride + 1;
+    const bool dense = n == 1 || frame_stride >= ext;               // frames do not interleave
+    int64_t dev_frame_stride = plane, dev_row_stride = width, dev_pixel_stride = 1, bytes = (int64_t)n * plane;
+    const uint8_t* src_host = s.in_host;
+    if (dense && frame_stride <= ext + 64 && (int64_t)(n - 1) * frame_stride + ext <= h->slot_bytes) {
+        // one contiguous span holds the whole chunk
+        bytes = (int64_t)(n - 1) * frame_stride + ext;
+        dev_frame_stride = frame_stride; dev_row_stride = row_stride; dev_pixel_stride = pixel_stride;
+        hipPointerAttribute_t attr;
+        const bool pinned = hipPointerGetAttributes(&attr, frames_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();                         // pageable memory: the query fails, clear it
+        if (pinned) src_host = frames_host;                           // direct DMA; caller keeps it valid until wait
+        else memcpy(s.in_host, frames_host, bytes);
+    } else if (dense && (int64_t)n * ext <= h->slot_bytes) {
+        // strided frames: one span per frame, packed back to back
+        for (int f = 0; f < n; ++f) memcpy(s.in_host + (int64_t)f * ext, frames_host + (int64_t)f * frame_stride, ext);
+        bytes = (int64_t)n * ext;
+        dev_frame_stride = ext; dev_row_stride = row_stride; dev_pixel_stride = pixel_stride;
+    } else {
+        // sparse layouts (huge strides): gather the consumed channel into packed planes on the host
+        if ((int64_t)n * plane > h->slot_bytes) return cbas_fail(CBAS_EINVAL, "chunk exceeds slot staging size");
+        for (int f = 0; f < n; ++f) {
+            const uint8_t* src = frames_host + (int64_t)f * frame_stride;
+            uint8_t* dst = s.in_host + (int64_t)f * plane;
             for (int y = 0; y < height; ++y) {
                 const uint8_t* r = src + (int64_t)y * row_stride;
                 uint8_t* d = dst + (int64_t)y * width;
@@ -658,7 +771,7 @@ extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* fra
             }
         }
     }
-    HIP_TRY(hipMemcpyAsync(s.in_dev, s.in_host, (int64_t)n * plane, hipMemcpyHostToDevice, h->copy));
+    HIP_TRY(hipMemcpyAsync(s.in_dev, src_host, bytes, hipMemcpyHostToDevice, h->copy));
     HIP_TRY(hipEventRecord(s.ev_copied, h->copy));
     const int lane = (int)(h->submit_count++ % (uint64_t)h->n_lanes);
     hipStream_t ls = h->lanes[lane].stream;
@@ -666,7 +779,8 @@ extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* fra
     rc = async_enter(h, lane, ls);
     if (rc) return rc;
     use_lane(h, lane);
-    rc = forward_u8(h, s.in_dev, n, height, width, plane, width, 1, s.out32_dev, s.out16_dev, ls, -1, -1);
+    rc = forward_u8(h, s.in_dev, n, height, width, dev_frame_stride, dev_row_stride, dev_pixel_stride, s.out32_dev,
+                    s.out16_dev, ls, -1, -1);
     use_lane(h, 0);
     if (rc) return rc;
     rc = async_leave(h, lane, ls);
@@ -720,6 +834,12 @@ extern "C" int cbas_enc_set_lanes(cbas_enc* h, int n_lanes) {
         if (s.busy) return cbas_fail(CBAS_ESTATE, "cbas_enc_set_lanes with a batch in flight");
     h->n_lanes = n_lanes;
     h->submit_count = 0;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_set_prune_last_layer(cbas_enc* h, int enable) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    h->prune_last = enable != 0;
     return CBAS_OK;
 }
 

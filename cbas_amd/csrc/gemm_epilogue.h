@@ -24,7 +24,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
             *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)orow * p.ldo + n) = v;
         }
     } else if (EPI == EPI_QKV) {
-        const int sec = head_col0 / p.D;               // 0 q, 1 k, 2 v: uniform over the 64-column group
+        const int sec = head_col0 / p.D + p.sec0;      // 0 q, 1 k, 2 v: uniform over the 64-column group
         const int t = m % p.tokens_per_frame;
         const bool rope = p.rope_cos && (sec < 2) && (t >= p.n_prefix);
         f32x4 v[4];
@@ -134,7 +134,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + head_col0 + j * 16 + g * 4);
-        const int sec = (EPI == EPI_QKV) ? head_col0 / p.D : 2;
+        const int sec = (EPI == EPI_QKV) ? head_col0 / p.D + p.sec0 : 2;
         const float qs = (sec == 0) ? 0.125f : 1.0f;
 #pragma unroll
         for (int half = 0; half < (TM + 3) / 4; ++half) {              // up to 64 rows per pass (8 KiB of scratch)

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16 ? 4 : 2)) void gemm_f1
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * BUF_BYTES;
-        stage_tile<BM, NW>(p.A, p.K, row0, p.M_pad - 1, kt * BK, base, wave, lane);
+        stage_tile<BM, NW>(p.A, p.lda, row0, p.M_pad - 1, kt * BK, base, wave, lane);
         stage_tile<BN, NW>(p.W, p.K, col0, p.N - 1, kt * BK, base + A_BYTES, wave, lane);
         if (NSPLIT == 2) stage_tile<BN, NW>(p.W_lo, p.K, col0, p.N - 1, kt * BK, base + A_BYTES + B_BYTES, wave, lane);
     };
@@ -173,6 +173,7 @@ int launch_epi(const GemmParams& p, int tile, hipStream_t stream) {
         case GEMM_TILE_128x256: return launch_one<EPI, 1, 2, 4>(p, stream);
         case GEMM_TILE_192x256: return launch_one<EPI, 1, 3, 4>(p, stream);
         case 12: return launch_one<EPI, 1, 2, 4, 8>(p, stream);      // 256x256, 8 waves x (128x64): experiment
+        case GEMM_TILE_64x128: return launch_one<EPI, 1, 1, 2>(p, stream);   // M <= 64: the CLS rows of the last layer
         default: return launch_one<EPI, 1, 2, 2>(p, stream);
     }
 }
@@ -186,6 +187,7 @@ int pick_tile(const GemmParams& p) {
     static const int forced = [] { const char* e = getenv("CBAS_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
     if (p.tile) return p.tile;
+    if (p.M <= 64 && !p.W_lo) return GEMM_TILE_64x128;
     // Measured with scripts/gemm_tiles.py at M = 12 864 (64 frames x 201 tokens), ViT-B shapes: the
     // 256x256 tile (16 waves, 1 workgroup per CU, 83 % MFMA-efficient main loop) wins on every
     // projection once there are enough tiles to occupy the chip; below that the 128x128 tile
@@ -199,7 +201,7 @@ int pick_tile(const GemmParams& p) {
             // the 8-wave ping-pong kernel (gemm_f16_8ph.hip) computes the same tiles bit-identically and
             // is 4-8 % faster on every projection; it consumes K-tiles in pairs and uses 32-bit offsets
             static const bool pp_off = [] { const char* e = getenv("CBAS_GEMM_PP"); return e && atoi(e) == 0; }();
-            const bool pp = !pp_off && p.K % 128 == 0 && (long long)p.M_pad * p.K < (1ll << 31) &&
+            const bool pp = !pp_off && p.K % 128 == 0 && (long long)p.M_pad * p.lda < (1ll << 31) &&
                             (long long)p.N * p.K < (1ll << 31);
             if (pp) return GEMM_TILE_PP_AUTO;          // its planner also knows 160-row tiles and 128-row tails
             return c192 < c256 ? GEMM_TILE_192x256 : GEMM_TILE_256x256;
@@ -211,8 +213,6 @@ int pick_tile(const GemmParams& p) {
 }  // namespace
 
 static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
-    if (tile == GEMM_TILE_RING_256x256_W16 || tile == GEMM_TILE_RING_256x256_W8 || (tile >= 8 && tile <= 11))
-        return launch_gemm_ring(epi, p, tile, stream);
     if (tile >= GEMM_TILE_PP_256x256 && tile <= GEMM_TILE_PP_AUTO) return launch_gemm_8ph(epi, p, tile, stream);
     switch (epi) {
         case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
@@ -227,8 +227,9 @@ int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     static const int gm_env = [] { const char* e = getenv("CBAS_GEMM_GM"); return e ? atoi(e) : 0; }();
     if (!p.group_m) p.group_m = gm_env > 0 ? gm_env : 1;
+    if (!p.lda) p.lda = p.K;
     if (p.N % 128 || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
-    if (epi == EPI_QKV && (p.D % 64 || p.N != 3 * p.D)) return -1;
+    if (epi == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;
     const int tile = pick_tile(p);
     int rc = dispatch_gemm(epi, p, tile, stream);
     if (rc == -1 && tile != GEMM_TILE_128x128) rc = dispatch_gemm(epi, p, GEMM_TILE_128x128, stream);   // shape not tileable that way

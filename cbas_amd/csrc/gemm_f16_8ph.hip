@@ -86,7 +86,7 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
             const int r = ar + lrow;
             int grow = row0 + r;
             grow = grow < p.M_pad - 1 ? grow : p.M_pad - 1;
-            a_src[h][s] = (unsigned)grow * (unsigned)p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+            a_src[h][s] = (unsigned)grow * (unsigned)p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
             const int qb = wave + 8 * s;
             const int br = (((qb >> 2) << 3) | (h << 2) | (qb & 3)) * 8;
             b_lds[h][s] = A_BYTES + br * 128;
@@ -351,7 +351,7 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
 
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
     // 32-bit element offsets into A / W; K-tiles are consumed in pairs
-    if (p.W_lo || p.N % 256 || p.K % (2 * BK) || (long long)p.M_pad * p.K >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31))
+    if (p.W_lo || p.N % 256 || p.K % (2 * BK) || (long long)p.M_pad * p.lda >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31))
         return -1;
     switch (epi) {
         case EPI_PATCH: return launch_8ph_epi<EPI_PATCH>(p, tile, stream);

@@ -15,9 +15,7 @@ enum GemmEpilogue {
 
 enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2, GEMM_TILE_128x256 = 3,
                 GEMM_TILE_256x256 = 4,
-                GEMM_TILE_RING_FIRST = 5,       // gemm_f16_ring.hip: 4-deep LDS ring, counted vmcnt
-                GEMM_TILE_RING_256x256_W16 = 5, GEMM_TILE_RING_256x256_W8 = 6,
-                GEMM_TILE_192x256 = 7,
+                GEMM_TILE_192x256 = 7, GEMM_TILE_64x128 = 8,
                 GEMM_TILE_PP_256x256 = 13,      // gemm_f16_8ph.hip: 8 waves, ping-pong phases, counted vmcnt
                 GEMM_TILE_PP_192x256 = 14, GEMM_TILE_PP_160x256 = 15, GEMM_TILE_PP_128x256 = 16,
                 GEMM_TILE_PP_AUTO = 17 };       // planner: uniform tile height, or 256-row tiles + 128-row tail
@@ -26,7 +24,8 @@ struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)
     int group_m;         // raster: row-panels per group (0/1 = N-fastest order)
     unsigned long long* stamps;   // bring-up only: per-block s_memtime stamps [grid][4], or nullptr
-    const f16* A;        // [M_pad][K]
+    const f16* A;        // [M_pad][lda]
+    int lda;             // row stride of A in elements (0: K).  lda = T*D reads one row per frame (the CLS rows)
     const f16* W;        // [N][K]  (hi part when split)
     const f16* W_lo;     // [N][K]  residual W - fp16(W) as fp16, or nullptr
     int M;               // valid rows (stores are skipped for rows >= M)
@@ -48,10 +47,10 @@ struct GemmParams {
     const float* rope_cos;   // [P][64], or nullptr: no RoPE (DINOv2)
     const float* rope_sin;   // [P][64]
     int D;                   // hidden size (q | k | v sections of width D)
+    int sec0;                // section of output column 0 (0: the full q|k|v GEMM; 1: W holds only k|v)
 };
 
 int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);
-int launch_gemm_ring(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
@@ -67,14 +66,17 @@ int launch_im2col_f32(const float* frames, int n, int height, int width, f16* A,
                       const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream);
 
 // LayerNorm over the last dim (fp32 in, fp16 out), rows = M
-int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, f16* out, int M, int D,
+// ldx = row stride of x in elements (D for the whole residual stream, T*D for the CLS rows only)
+int launch_layernorm_f16(const float* x, int64_t ldx, const float* gamma, const float* beta, f16* out, int M, int D,
                          float eps, hipStream_t stream);
 // Final LayerNorm on the CLS row of every frame: x[b*T] -> cls_f32[b][D] / cls_f16[b][D]
 int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
                           f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream);
 
 // Multi-head attention over frames: qkv16 [n*T][3D] (q pre-scaled by 1/8, RoPE applied) -> o16 [n*T][D]
-int launch_attention(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream);
+// q_cls != nullptr: only the CLS query of every frame (the last layer: [tf]:540-541 + cbas.py:677 consume row 0
+// alone): q_cls [n][D] holds the projected CLS queries, out is then [n][D]; K and V still come from qkv.
+int launch_attention(const f16* qkv, const f16* q_cls, f16* out, int n, int T, int D, int n_heads, hipStream_t stream);
 
 // fp32 -> fp16 weight conversion (optionally also the fp16 residual), n elements
 int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t stream);

@@ -120,14 +120,14 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
 }
 
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, f16* __restrict__ out,
                                                             int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     f32x4 y[NV];
-    ln_row<NV>(x + (size_t)row * D, gamma, beta, D, eps, lane, y);
+    ln_row<NV>(x + (size_t)row * ldx, gamma, beta, D, eps, lane, y);
     const int nvec = D >> 2;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -180,8 +180,8 @@ __device__ __forceinline__ int v_off(int row, int col) {   // col in halves
 // ONE partial tile is masked (4 compares per lane, once) and fully padded tiles cost no MFMA; the
 // run-time form costs a compare+select per score because hipcc if-converts the tail test.
 template <int NKT, int NV>
-__global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
-                                                                            int T, int D, int n_heads) {
+__global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
+                                                                            f16* __restrict__ out, int T, int D, int n_heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = NKT * 16;
     constexpr int NQK = NV ? NV : NKT;                 // key tiles that need S = K Q^T
@@ -196,13 +196,18 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
     const f16* kbase = qbase + D;
     const f16* vbase = qbase + 2 * D;
     const int g = lane >> 4, li = lane & 15;
-    const int nqt = (T + 15) >> 4;
+    // CLS-query mode (last layer): one query per frame, read from the compact q_cls [n][D]; all 16 query
+    // slots of the tile carry that row (each MFMA column depends on its own query only), slot 0 is stored
+    const int nq = q_cls ? 1 : T;
+    const f16* qsrc = q_cls ? q_cls + (size_t)b * D + hd * 64 : qbase;
+    const size_t qld = q_cls ? 0 : ld;
+    const int nqt = (nq + 15) >> 4;
 
     auto load_q = [&](int qt, f16x8 (&qf)[2]) {
         const int q = qt * 16 + li;
-        const int qrow = q < T ? q : T - 1;
-        qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
-        qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
+        const int qrow = q < nq ? q : nq - 1;
+        qf[0] = *reinterpret_cast<const f16x8*>(qsrc + (size_t)qrow * qld + g * 8);
+        qf[1] = *reinterpret_cast<const f16x8*>(qsrc + (size_t)qrow * qld + 32 + g * 8);
     };
     // Q of this wave's first tile is fetched before the K/V staging so its latency hides under it
     f16x8 qf[2] = {}, qn[2] = {};
@@ -303,9 +308,9 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
             for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt], pf[s2], o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (q < T) {
+        if (q < nq) {
             const float inv = 1.0f / sum;
-            f16* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * g;
+            f16* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const f32x4 w = o[dt] * inv;
@@ -325,8 +330,8 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
 // S^T = K Q^T / P^T-as-B-operand / transposing-read-of-V layout as the resident kernel: a lane's
 // accumulators all belong to ONE query, so the rescale is a per-lane scalar.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __restrict__ qkv, f16* __restrict__ out,
-                                                                  int T, int D, int n_heads) {
+__global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
+                                                                  f16* __restrict__ out, int T, int D, int n_heads) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];    // [buf][K|V][64 keys][128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / n_heads, hd = blockIdx.x - b * n_heads;
@@ -337,10 +342,13 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
     const int g = lane >> 4, li = lane & 15;
     const int nkb = (T + 63) >> 6;
     const int q = (blockIdx.y * 8 + wave) * 16 + li;
-    const int qrow = q < T ? q : T - 1;
+    const int nq = q_cls ? 1 : T;                              // CLS-query mode: see attention_kernel
+    const bool wave_active = (blockIdx.y * 8 + wave) * 16 < nq;   // wave-uniform; idle waves still stage K/V
+    const int qrow = q < nq ? q : nq - 1;
+    const f16* qsrc = q_cls ? q_cls + (size_t)b * D + hd * 64 : qbase + (size_t)qrow * ld;
     f16x8 qf[2];
-    qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
-    qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
+    qf[0] = *reinterpret_cast<const f16x8*>(qsrc + g * 8);
+    qf[1] = *reinterpret_cast<const f16x8*>(qsrc + 32 + g * 8);
 
     const int sr = tid >> 3, sc = tid & 7;                     // staging: one 16-byte chunk of K and of V per thread
     auto load_blk = [&](int kb, f16x8& kv, f16x8& vv) {
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
         if (kb + 1 < nkb) load_blk(kb + 1, kv, vv);
         const char* Ks = smem + (kb & 1) * 16384;
         const char* Vs = Ks + 8192;
+        if (wave_active) {
         f32x4 s[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -425,14 +434,15 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[s2], o[dt], 0, 0, 0);
             }
         }
+        }
         if (kb + 1 < nkb) store_blk((kb + 1) & 1, kv, vv);
         __syncthreads();
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (q < T) {
+    if (q < nq) {
         const float inv = 1.0f / l;
-        f16* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * g;
+        f16* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const f32x4 w = o[dt] * inv;
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
 }
 
 template <int NKT, int NV>
-int launch_attention_t(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
+int launch_attention_t(const f16* qkv, const f16* q_cls, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
     constexpr int lds = NKT * 16 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -455,8 +465,9 @@ int launch_attention_t(const f16* qkv, f16* out, int n, int T, int D, int n_head
     // at most 8 waves (a 1024-thread bound caps the kernel at 128 VGPRs and it spills); the fewest waves that keep
     // every wave equally loaded: T = 201 -> 13 tiles -> 7 waves x 2, T = 261 -> 17 tiles -> 6 waves x 3
     constexpr int maxw = 8;                  // measured: 13 waves x 1 tile (35 us) loses to 7 waves x 2 tiles (29.6 us) at T = 201
-    const int nqt = (T + 15) / 16, rounds = (nqt + maxw - 1) / maxw, nwaves = (nqt + rounds - 1) / rounds;
-    hipLaunchKernelGGL((attention_kernel<NKT, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, out, T, D, n_heads);
+    const int nqt = (T + 15) / 16, rounds = (nqt + maxw - 1) / maxw;
+    const int nwaves = q_cls ? 4 : (nqt + rounds - 1) / rounds;       // CLS mode: one query tile, 4 waves stage K/V
+    hipLaunchKernelGGL((attention_kernel<NKT, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, q_cls, out, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -521,15 +532,15 @@ int launch_im2col_f32(const float* frames, int n, int height, int width, f16* A,
     return CHECK_LAUNCH();
 }
 
-int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, f16* out, int M, int D,
+int launch_layernorm_f16(const float* x, int64_t ldx, const float* gamma, const float* beta, f16* out, int M, int D,
                          float eps, hipStream_t stream) {
     const int nv = (D / 4 + 63) / 64;
     const dim3 grid((M + 3) / 4), block(256);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_f16_kernel<1>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
-        case 2: hipLaunchKernelGGL(layernorm_f16_kernel<2>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
-        case 3: hipLaunchKernelGGL(layernorm_f16_kernel<3>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
-        case 4: hipLaunchKernelGGL(layernorm_f16_kernel<4>, grid, block, 0, stream, x, gamma, beta, out, M, D, eps); break;
+        case 1: hipLaunchKernelGGL(layernorm_f16_kernel<1>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_f16_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_f16_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 4: hipLaunchKernelGGL(layernorm_f16_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
         default: return -1;
     }
     return CHECK_LAUNCH();
@@ -549,19 +560,19 @@ int launch_final_norm_cls(const float* x, const float* gamma, const float* beta,
     return CHECK_LAUNCH();
 }
 
-int launch_attention(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
+int launch_attention(const f16* qkv, const f16* q_cls, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
     const int nkt = (T + 15) / 16;
     // exact-tile-count instantiations for the sequence lengths CBAS produces: 224x224 /16 -> T = 201 (13 tiles),
     // 256x256 /16 and 224x224 /14 -> T = 261 (17 tiles); everything else takes the run-time-masked form
-    if (nkt == 13) return launch_attention_t<14, 13>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt == 17) return launch_attention_t<18, 17>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 2) return launch_attention_t<2, 0>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 6) return launch_attention_t<6, 0>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 14) return launch_attention_t<14, 0>(qkv, out, n, T, D, n_heads, stream);
-    if (nkt <= 18) return launch_attention_t<18, 0>(qkv, out, n, T, D, n_heads, stream);
+    if (nkt == 13) return launch_attention_t<14, 13>(qkv, q_cls, out, n, T, D, n_heads, stream);
+    if (nkt == 17) return launch_attention_t<18, 17>(qkv, q_cls, out, n, T, D, n_heads, stream);
+    if (nkt <= 2) return launch_attention_t<2, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
+    if (nkt <= 6) return launch_attention_t<6, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
+    if (nkt <= 14) return launch_attention_t<14, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
+    if (nkt <= 18) return launch_attention_t<18, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
     // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
-    const int nqb = ((T + 15) / 16 + 7) / 8;
-    hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, out, T, D, n_heads);
+    const int nqb = q_cls ? 1 : ((T + 15) / 16 + 7) / 8;
+    hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -222,6 +222,10 @@ class DinoEncoder:
         """1 or 2 compute lanes for the asynchronous forms (default 2: two batches in flight)."""
         _lib.check(self._lib.cbas_enc_set_lanes(self._h, int(n)), "cbas_enc_set_lanes")
 
+    def set_prune_last_layer(self, enable: bool) -> None:
+        """Default on: the last layer computes q/attention/MLP for the CLS rows only (bit-identical CLS)."""
+        _lib.check(self._lib.cbas_enc_set_prune_last_layer(self._h, int(bool(enable))), "cbas_enc_set_prune_last_layer")
+
     def wait_stream(self, slot: int) -> None:
         """The current torch stream waits for ``slot``'s batch (no host synchronisation); frees the slot."""
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -49,7 +49,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   5
+#define CBAS_ABI_VERSION   6
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -107,7 +107,12 @@ int cbas_enc_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int heigh
  * submit copies the pixels host->HBM on the handle's copy stream (from pinned staging), encodes
  * on the compute stream and copies the CLS rows back; wait blocks until that slot is done and
  * writes n*D halves (and/or floats).  Submitting to slot s while s is busy is CBAS_ESTATE.
- * Different slots overlap: copy(s+1) runs under compute(s). */
+ * Different slots overlap: copy(s+1) runs under compute(s).
+ * The caller's bytes travel as they are (interleaved RGB included: 150 KB per 224x224 frame is nothing on PCIe 5)
+ * and the consumed channel is picked on the device through the strides - the host does no per-pixel work.
+ * Pageable memory is copied into the slot's pinned staging before the call returns.  If frames_host is itself
+ * pinned (hipHostMalloc / hipHostRegister, e.g. a torch pin_memory() tensor) the H2D copy is a direct DMA from it and
+ * the caller must leave those bytes untouched until cbas_enc_wait(slot). */
 #define CBAS_ENC_SLOTS 3
 int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
                             int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride);
@@ -128,6 +133,11 @@ int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream);
 /* Use 1 or 2 compute lanes for the asynchronous forms (2 by default; 1 serialises the batches, e.g. to time
  * kernels without another batch's kernels running beside them).  No batch may be in flight. */
 int cbas_enc_set_lanes(cbas_enc* h, int n_lanes);
+/* The reference runs its last transformer layer on every token and then keeps row 0 ([tf]:540-541,
+ * backend/cbas.py:677).  By default the last layer here projects K and V for all rows but computes the query,
+ * attention, o_proj, LayerNorm 2 and the MLP for the n CLS rows only (rows are independent: the CLS output is
+ * bit-identical).  enable = 0 restores the full last layer (used by the tests that prove the identity). */
+int cbas_enc_set_prune_last_layer(cbas_enc* h, int enable);
 
 /* Bring-up/debug: run the forward pass only up to (layer, stage) and copy an internal buffer to
  * the host.  stage: 0 embeddings (x), then per layer 1 LN1(h16) 2 QKV(qkv16) 3 attention(h16)

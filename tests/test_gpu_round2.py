@@ -1,0 +1,138 @@
+"""Round-2 GPU tests of the encoder's host/runtime behaviour (all through the C ABI):
+
+* the pruned last layer (query/attention/MLP on the CLS rows only) is bit-identical to the full one,
+  for the LDS-resident and the streaming attention kernels;
+* cbas_enc_submit_u8_host ships the caller's bytes as they are (RGB interleaved, packed plane, strided
+  frames, pinned or pageable memory) and always gives the device-resident result bit for bit;
+* a queue that mixes resolutions needs no device synchronisation and stays correct;
+* two synchronous forwards on different caller streams are ordered by the library.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cbas_amd import config as C, weights as W, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(cfgname, max_batch, hw):
+    from cbas_amd.encoder import DinoEncoder
+    cfg = C.NAMED_VIT[cfgname]
+    return cfg, DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=max_batch,
+                                         max_frame=hw)
+
+
+@pytest.mark.parametrize("cfgname,n,hw", [("vitb16", 64, (224, 224)),      # bench shape, resident attention (T=201)
+                                          ("vits16", 5, (320, 336)),       # T=425: streaming attention
+                                          ("tiny", 7, (64, 64)),
+                                          ("dinov2regtiny", 3, (70, 70))])
+def test_pruned_last_layer_is_bit_identical(cfgname, n, hw):
+    cfg, enc = _enc(cfgname, n, hw)
+    try:
+        fr = torch.from_numpy(synth.noise_frames(3, n, *hw)).cuda()
+        enc.set_prune_last_layer(False)
+        f16, f32 = enc.encode_u8(fr)
+        enc.set_prune_last_layer(True)
+        p16, p32 = enc.encode_u8(fr)
+        torch.cuda.synchronize()
+        assert torch.isfinite(f32).all()
+        assert torch.equal(f32, p32) and torch.equal(f16, p16)
+        # and the float-input entry point (DinoEncoder.forward) takes the same pruned path
+        x = (fr[:, :, :, 1].float() / 255.0).unsqueeze(1)
+        a = enc(x)
+        enc.set_prune_last_layer(False)
+        b = enc(x)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    finally:
+        enc.close()
+
+
+def test_host_submission_layouts_match_device_path():
+    cfg, enc = _enc("tiny", 8, (64, 64))
+    try:
+        rgb = synth.cage_frames(21, 8, 64, 64)                            # (8,64,64,3) uint8, pageable
+        ref16, ref32 = enc.encode_u8(torch.from_numpy(rgb).cuda())
+        torch.cuda.synchronize()
+        ref16, ref32 = ref16.cpu().numpy(), ref32.cpu().numpy()
+
+        def run(arr, **kw):
+            enc.submit_host(0, arr, **kw)
+            o16, o32 = enc.wait(0, want_f32=True)
+            assert np.array_equal(o16.view(np.uint16), ref16.view(np.uint16)) and np.array_equal(o32, ref32)
+
+        run(rgb)                                                          # pageable interleaved RGB: one span
+        pinned = torch.from_numpy(rgb).pin_memory()
+        run(pinned.numpy())                                               # pinned: direct DMA from the caller's bytes
+        run(np.ascontiguousarray(rgb[:, :, :, 1]))                        # packed green plane
+        # frames strided apart (a view into a larger buffer): one span per frame
+        wide = np.zeros((8, 2, 64, 64, 3), np.uint8)
+        wide[:, 0] = rgb
+        from cbas_amd import _lib
+        fs = wide.strides[0]
+        _lib.check(enc._lib.cbas_enc_submit_u8_host(enc._h, 1, wide.ctypes.data + 1, 8, 64, 64, fs, 64 * 3, 3),
+                   "cbas_enc_submit_u8_host")
+        enc._slot_n = {1: 8}
+        o16, o32 = enc.wait(1, want_f32=True)
+        assert np.array_equal(o32, ref32)
+        # sparse layout (pixel stride 16): falls back to the host gather, same result
+        sparse = np.zeros((8, 64, 64, 16), np.uint8)
+        sparse[..., 5] = rgb[..., 1]
+        _lib.check(enc._lib.cbas_enc_submit_u8_host(enc._h, 2, sparse.ctypes.data + 5, 8, 64, 64, 64 * 64 * 16, 64 * 16, 16),
+                   "cbas_enc_submit_u8_host")
+        enc._slot_n = {2: 8}
+        assert np.array_equal(enc.wait(2, want_f32=True)[1], ref32)
+    finally:
+        enc.close()
+
+
+def test_mixed_resolution_queue():
+    """Batches of different frame sizes alternate on the two lanes; each resolution's RoPE table lives in its own
+    buffers, so no batch reads a table that a later batch's resolution overwrote."""
+    from cbas_amd import _lib as L
+    cfg, enc = _enc("tiny", 8, (96, 96))
+    try:
+        sizes = [(64, 64), (96, 96), (64, 96), (80, 48), (64, 64), (96, 96), (48, 80), (64, 96), (32, 32), (96, 64)]
+        frames = [torch.from_numpy(synth.cage_frames(30 + i, 8, h, w)).cuda() for i, (h, w) in enumerate(sizes)]
+        ref = []
+        for f in frames:
+            ref.append(enc.encode_u8(f, want_f32=False)[0].clone())
+        torch.cuda.synchronize()
+        for rep in range(3):
+            outs = [torch.zeros_like(r) for r in ref]
+            busy = []
+            for i, f in enumerate(frames):
+                slot = i % L.ENC_SLOTS
+                if slot in busy:
+                    enc.wait_stream(slot)
+                    busy.remove(slot)
+                enc.submit_dev(slot, f, outs[i])
+                busy.append(slot)
+            for slot in busy:
+                enc.wait_stream(slot)
+            torch.cuda.synchronize()
+            for i in range(len(frames)):
+                assert torch.equal(outs[i], ref[i]), (rep, i, sizes[i])
+    finally:
+        enc.close()
+
+
+def test_two_synchronous_forwards_on_different_streams():
+    cfg, enc = _enc("tiny", 16, (64, 64))
+    try:
+        fa = torch.from_numpy(synth.cage_frames(41, 16, 64, 64)).cuda()
+        fb = torch.from_numpy(synth.cage_frames(42, 16, 64, 64)).cuda()
+        ra = enc.encode_u8(fa, want_f32=False)[0].clone()
+        rb = enc.encode_u8(fb, want_f32=False)[0].clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for rep in range(8):
+            with torch.cuda.stream(s1):
+                a = enc.encode_u8(fa, want_f32=False)[0]
+            with torch.cuda.stream(s2):
+                b = enc.encode_u8(fb, want_f32=False)[0]
+            torch.cuda.synchronize()
+            assert torch.equal(a, ra) and torch.equal(b, rb), rep
+    finally:
+        enc.close()
