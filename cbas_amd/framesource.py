@@ -129,7 +129,11 @@ class PipeFrameSource:
         self._prefetch = int(prefetch_frames)
         self._q: "queue.Queue" = queue.Queue(maxsize=queue_depth)
         self._pending: List[np.ndarray] = []
-        self._proc = subprocess.Popen(fmt(decode_cmd or self.DECODE_CMD), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        # the decoder's stderr goes to an unnamed temp file, not a pipe: a pipe nobody drains blocks the decoder
+        # (and with it get_batch) once ~64 KB of warnings have accumulated
+        import tempfile
+        self._errf = tempfile.TemporaryFile()
+        self._proc = subprocess.Popen(fmt(decode_cmd or self.DECODE_CMD), stdout=subprocess.PIPE, stderr=self._errf,
                                       bufsize=1 << 20)
         head = self._proc.stdout.readline(256)
         if not head and self._n == 0:
@@ -139,7 +143,7 @@ class PipeFrameSource:
             try:
                 self.width, self.height, self._fsize = _parse_y4m_header(head)
             except ValueError as e:
-                err = self._proc.stderr.read().decode(errors="replace")
+                err = self._stderr_tail()
                 self.close()
                 raise RuntimeError(f"decoder for {path!r} did not produce a Y4M stream: {e}; stderr: {err[-400:]}") from e
         self._stop = threading.Event()
@@ -172,6 +176,19 @@ class PipeFrameSource:
         except Exception as e:  # noqa: BLE001   surfaced to the consumer by get_batch
             self._put(e)
 
+    def _stderr_tail(self, n: int = 400) -> str:
+        try:
+            self._proc.wait(timeout=2)
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            self._errf.seek(0, 2)
+            size = self._errf.tell()
+            self._errf.seek(max(0, size - n))
+            return self._errf.read().decode(errors="replace")
+        except Exception:  # noqa: BLE001
+            return ""
+
     def _put(self, item):
         while not self._stop.is_set():
             try:
@@ -192,7 +209,14 @@ class PipeFrameSource:
         need, parts = len(idx), []
         while need > 0:
             if not self._pending:
-                item = self._q.get()
+                while True:                       # never wait forever on a decoder that died without closing its pipe
+                    try:
+                        item = self._q.get(timeout=1.0)
+                        break
+                    except queue.Empty:
+                        if not self._thread.is_alive() and self._q.empty():
+                            raise EOFError(f"{self.path}: decoder thread ended without delivering frame {self._next}; "
+                                           f"stderr: {self._stderr_tail()}") from None
                 if item is None:
                     raise EOFError(f"{self.path}: decoder delivered {self._next + len(idx) - need} frames, container reports {self._n}")
                 if isinstance(item, Exception):
@@ -218,7 +242,7 @@ class PipeFrameSource:
                 p.kill()
             except OSError:
                 pass
-            for s in (p.stdout, p.stderr):
+            for s in (p.stdout, getattr(self, "_errf", None)):
                 try:
                     s.close()
                 except Exception:  # noqa: BLE001

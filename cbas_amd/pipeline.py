@@ -286,19 +286,30 @@ def write_probs_csv(path: str, probs: np.ndarray, behaviors: List[str]) -> None:
             f.write(format_probs_csv(probs, behaviors))
 
 
-_head_cache = {}
+_head_cache = {}       # single entry: id(module) -> (weakref to the module, parameter versions, device head)
+
+
+def _param_versions(model):
+    # torch bumps Tensor._version on every in-place update (optimizer.step, load_state_dict, .copy_): together with
+    # the storage address this fingerprints "the same weights as when the device copy was made"
+    return tuple((p.data_ptr(), p._version) for p in model.state_dict().values())
 
 
 def _as_mi355x_head(model, device) -> ClassifierLSTMDeltas:
+    """A reference ``classifier_head.ClassifierLSTMDeltas`` is mirrored on the device once and reused while it is the
+    same live module with unchanged weights; further training, ``load_state_dict`` or a new module that happens to
+    reuse the old one's ``id`` all rebuild the device copy (the head is ~2 MB)."""
     if isinstance(model, ClassifierLSTMDeltas):
         return model.to(device)
-    key = id(model)
-    if key not in _head_cache:
-        if not (hasattr(model, "state_dict") and hasattr(model, "seq_len")):
-            raise TypeError(f"cannot run {type(model).__name__} on the MI355X head")
+    if not (hasattr(model, "state_dict") and hasattr(model, "seq_len")):
+        raise TypeError(f"cannot run {type(model).__name__} on the MI355X head")
+    import weakref
+    key, ver = id(model), _param_versions(model)
+    hit = _head_cache.get(key)
+    if hit is None or hit[0]() is not model or hit[1] != ver:
         _head_cache.clear()
-        _head_cache[key] = from_reference_module(model, device)
-    return _head_cache[key].to(device)
+        _head_cache[key] = (weakref.ref(model), ver, from_reference_module(model, device))
+    return _head_cache[key][2].to(device)
 
 
 def infer_file(file_path: str, model, dataset_name: str, behaviors: List[str], seq_len: int, device=None,

@@ -136,3 +136,56 @@ def test_two_synchronous_forwards_on_different_streams():
             assert torch.equal(a, ra) and torch.equal(b, rb), rep
     finally:
         enc.close()
+
+
+class _RefLikeHead(torch.nn.Module):
+    """The attribute / state_dict surface of the reference's classifier_head.ClassifierLSTMDeltas (what
+    from_reference_module reads); no forward - the MI355X head does the arithmetic."""
+
+    def __init__(self, I=768, Cn=9, T=31, h=64):
+        super().__init__()
+        nn = torch.nn
+        self.in_features, self.out_features, self.seq_len, self.sw, self.ema_alpha = I, Cn, T, 5, 0.3
+        self.gate = nn.Parameter(torch.zeros(1))
+        self.attention_temp = nn.Parameter(torch.zeros(1))
+        for s in ("cls", "delta", "acc"):
+            setattr(self, f"{s}_bottleneck", nn.Sequential(nn.Linear(I, 128)))
+            setattr(self, f"{s}_ln", nn.LayerNorm(128))
+        self.lin0 = nn.Sequential(nn.Linear(384, 256))
+        self.lstm = nn.LSTM(256, h, num_layers=1, batch_first=True, bidirectional=True)
+        self.attention_head = nn.Linear(2 * h, 1)
+        self.lin1 = nn.Linear(I, Cn)
+        self.lin2 = nn.Linear(2 * h, Cn)
+
+
+def test_infer_file_follows_weight_updates_of_a_reference_module(tmp_path):
+    """the device copy of a reference torch head is rebuilt when the module is trained further or
+    reloaded in place, or when a new module reuses a freed module's id."""
+    from cbas_amd import pipeline as P, h5io
+    from oracle import pipeline_oracle as PO
+    names = [f"b{i}" for i in range(9)]
+    hcfg = C.HeadConfig()
+    w1, w2 = W.synth_head_weights(hcfg, 4321), W.synth_head_weights(hcfg, 99)
+    cls = (np.random.default_rng(0).standard_normal((300, 768)) * 2).astype(np.float16)
+    path = str(tmp_path / "v_cls.h5")
+    with h5io.ClsWriter(path, 768, {}) as w:
+        w.append(cls)
+
+    def run(model):
+        out = P.infer_file(path, model, "m", names, 31, device="cuda")
+        assert out is not None
+        return np.loadtxt(out, delimiter=",", skiprows=1, dtype=np.float32)
+
+    m = _RefLikeHead()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w1.items()})
+    p1 = run(m)
+    np.testing.assert_allclose(p1, PO.classify_cls(cls, w1, 31, 1.0), atol=1e-4)
+    assert np.array_equal(run(m), p1)                                   # cached copy reused: same result
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w2.items()})  # in-place update of the same module
+    p2 = run(m)
+    np.testing.assert_allclose(p2, PO.classify_cls(cls, w2, 31, 1.0), atol=1e-4)
+    assert np.abs(p2 - p1).max() > 1e-3
+    with torch.no_grad():                                               # one optimiser-style in-place step
+        m.lin1.bias.add_(0.5)
+    w3 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    np.testing.assert_allclose(run(m), PO.classify_cls(cls, w3, 31, 1.0), atol=1e-4)

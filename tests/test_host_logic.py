@@ -67,7 +67,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     loaded = _lib.load()
-    assert loaded.cbas_abi_version() == 5
+    assert loaded.cbas_abi_version() == _lib.EXPECTED_ABI
 
 
 def test_weight_counts_agree_between_host_and_library():
