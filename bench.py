@@ -5,13 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): DINOv3 ViT-B/16, synthetic 224x224 RGB uint8 clip resident in
-HBM, batch 64, chunked encode -> fp16 CLS -> sliding-window BiLSTM head (C=9, seq_len 31).
-One *step* = one 64-frame batch through the encoder, plus the head over every frame whose
-31-frame window has become complete (classified in groups, the tail inside the timed region).
-Weights are synthetic (seeded, counter-based): the real checkpoints are gated and there is no
-network.  With N > 1 each rank streams its own clip (weak scaling, no data-path collective) and the
-output rows are gathered to rank 0 over RCCL inside the timed region.
+Workload (BASELINE.json configs[1]): DINOv3 ViT-B/16, synthetic 224x224 RGB uint8 clip, batch 64, chunked
+encode -> fp16 CLS -> sliding-window BiLSTM head (C=9, seq_len 31).  One *step* = one 64-frame batch through
+the encoder, plus the head over every frame whose 31-frame window has become complete (classified in groups,
+the tail inside the timed region).  Weights are synthetic (seeded, counter-based): the real checkpoints are
+gated and there is no network.  With N > 1 each rank streams its own clip (weak scaling, no data-path
+collective) and the output rows are gathered to rank 0 over RCCL inside the timed region.
+
+Three passes over the same K steps:
+  1. `value`: frames already resident in HBM when the clock starts, results left in HBM (the bench contract);
+  2. `host_path`: SURVEY section 8(d)'s end-to-end form - uint8 RGB in pinned host memory ->
+     cbas_fused_push_u8_host (PCIe H2D on the copy stream) -> encoder -> head -> fp16 CLS rows + fp32
+     probabilities back in host memory; reported beside `value`, never as `value`;
+  3. per-kernel HIP-event timing for `roofline` (one batch in flight).
+`gates` = the correctness gates of section 8(d) evaluated in this very process against the fixtures made from the
+reference (tests/golden): CLS relative error on the golden frames, head label mismatches on golden rows.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
@@ -41,34 +49,67 @@ SEQ_LEN = 31
 
 
 def cpu_baseline(model: str, hw: int, frames: int, batch: int) -> dict:
-    """The oracle (CPU float32 restatement of the reference path) timed on this box's host cores,
-    on a bounded sample of the same workload.  Never used as the product path."""
+    """The oracle (CPU float32 restatement of the reference path, torch CPU ops - what the reference's own CPU
+    path runs on) timed on this box's host cores, on a bounded sample of the same workload.  Checker only: never
+    the product path."""
     from oracle import pipeline_oracle as PO
+    from oracle import vit_oracle_torch as VT
     # use the cores this process may run on (the GPU box gives a CPU share, not the whole host)
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
-    threads = max(1, min(threads, int(os.environ.get("CBAS_CPU_BASELINE_THREADS", "32"))))
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
-    except Exception:  # noqa: BLE001
-        limiter = None
+    threads = max(1, min(threads, int(os.environ.get("CBAS_CPU_BASELINE_THREADS", "64"))))
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     cfg = C.NAMED_VIT[model]
     hcfg = C.HeadConfig(in_features=cfg.hidden_size, out_features=BEHAVIORS, seq_len=SEQ_LEN)
-    enc_w = W.synth_encoder_weights(cfg, 1234)
+    enc_w = VT.to_torch(W.synth_encoder_weights(cfg, 1234))
     head_w = W.synth_head_weights(hcfg, 4321)
     fr = synth.noise_frames(0, frames, hw, hw)
-    PO.encode_and_classify(fr[:batch], enc_w, cfg, head_w, SEQ_LEN, batch)        # warm-up batch
+
+    def run(f):
+        cls32 = VT.encode_frames(f, enc_w, cfg, batch)
+        return PO.classify_cls(cls32.astype(np.float16), head_w, SEQ_LEN, 1.0)
+    run(fr[:batch])                                   # warm-up batch
     t0 = time.perf_counter()
-    PO.encode_and_classify(fr, enc_w, cfg, head_w, SEQ_LEN, batch)
+    run(fr)
     dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
+    torch.set_num_threads(old_threads)
     return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{frames} frames of the same workload ({model} {hw}x{hw}, batch {batch}, fp32 numpy/BLAS "
-                      f"oracle incl. LSTM head), {dt:.1f} s wall"}
+            "sample": f"{frames} frames of the same workload ({model} {hw}x{hw}, batch {batch}, fp32 torch-CPU "
+                      f"restatement of the encoder (oracle/vit_oracle_torch.py) + numpy LSTM head), {dt:.1f} s wall"}
+
+
+def gates(enc, head, model: str, hw: int, precision: int) -> dict:
+    """SURVEY section 8(d) 'correctness gates reported with every number', against fixtures generated from the
+    reference (tests/golden/make_goldens.py): max per-frame ||CLS - ref||2 / ||ref||2 on the golden frames of this
+    model/resolution, and argmax mismatches of the head on the reference's 700-frame infer_file golden."""
+    gd = os.path.join(HERE, "tests", "golden")
+    out = {"cls_tol": 1e-3 if precision < 2 else None}
+    name = {("vitb16", 224): "vitb16_224_noise", ("vitb16", 256): "vitb16_256", ("vits16", 224): "vits16_224",
+            ("vitl16", 224): "vitl16_224", ("vitl16", 518): "vitl16_518"}.get((model, hw))
+    path = os.path.join(gd, f"{name}.npz") if name else None
+    if path and os.path.exists(path):
+        g = np.load(path)
+        mk = synth.noise_frames if str(g["kind"]) == "noise" else synth.cage_frames
+        fr = mk(int(g["frame_seed"]), int(g["n"]), hw, hw)
+        _, c32 = enc.encode_u8(torch.from_numpy(fr).to(enc.device))
+        c32 = c32.cpu().numpy().astype(np.float64)
+        ref = g["cls"].astype(np.float64)
+        rel = np.linalg.norm(c32 - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        out.update(cls_rel_err_max=float(f"{rel.max():.3e}"), cls_frames=int(len(rel)), cls_fixture=f"{name}.npz")
+    else:
+        out.update(cls_rel_err_max=None, cls_frames=0, cls_fixture=None)
+    ip = os.path.join(gd, "infer_file.npz")
+    if os.path.exists(ip) and head.in_features == 768 and head.out_features == BEHAVIORS:
+        g = np.load(ip)
+        cls = torch.from_numpy(synth.cls_walk(100 + 700, 700, 768)).to(enc.device)
+        pr = head.infer_clip(cls, float(g["temp_700"])).cpu().numpy()
+        ref = g["probs_700"]
+        out.update(head_label_mismatches=int((pr.argmax(1) != ref.argmax(1)).sum()), head_frames=700,
+                   head_prob_err_max=float(f"{np.abs(pr - ref).max():.3e}"), head_fixture="infer_file.npz[probs_700]")
+    return out
 
 
 def main() -> None:
@@ -80,9 +121,11 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--precision", type=int, default=0)
-    ap.add_argument("--cpu-frames", type=int, default=32)
+    ap.add_argument("--cpu-frames", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-gates", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (compute lanes of the encoder)")
     args = ap.parse_args()
 
@@ -120,6 +163,12 @@ def main() -> None:
     gen.manual_seed(1000 + rank)
     clip = torch.randint(0, 256, (n_res, args.hw, args.hw, 3), dtype=torch.uint8, device=device, generator=gen)
     stream = ClipStream(enc, head, capacity=max(K, Wm) * B, classify_every=1024)
+    # the same clip in pinned host memory for the host_path pass (decord hands encode_file host arrays)
+    clip_host = None
+    if not args.no_host_path:
+        clip_host_t = torch.empty((n_res, args.hw, args.hw, 3), dtype=torch.uint8).pin_memory()
+        clip_host_t.copy_(clip)
+        clip_host = clip_host_t.numpy()
 
     def run(steps: int):
         stream.reset()
@@ -127,6 +176,13 @@ def main() -> None:
             o = (s * B) % n_res
             stream.push_u8(clip[o:o + B])
         return stream.finish()
+
+    def run_host(steps: int):
+        stream.reset()
+        for s in range(steps):
+            o = (s * B) % n_res
+            stream.push_host(clip_host[o:o + B])
+        return stream.finish_host()               # numpy arrays in host memory
 
     def gather(cls16, probs):
         if world > 1:
@@ -148,8 +204,28 @@ def main() -> None:
         cdist.barrier()
         return cdist.max_over_ranks(time.perf_counter() - t0, device)
 
+    def timed_host():
+        cdist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        c16h, prh = run_host(K)
+        if world > 1:
+            gather(torch.from_numpy(c16h).to(device), torch.from_numpy(prh).to(device))
+        torch.cuda.synchronize(device)
+        cdist.barrier()
+        return cdist.max_over_ranks(time.perf_counter() - t0, device), c16h, prh
+
     # pass 1: the timed region proper (EXACTLY K steps, nothing instrumented) -> value
     dt = timed()
+    # pass 1b: the same K steps from pinned host memory, results back in host memory -> host_path
+    dt_host, host_equal = None, None
+    if clip_host is not None:
+        run_host(max(Wm, 1))
+        dt_host, c16h, prh = timed_host()
+        c16d, prd = run(K)                        # the two passes must agree bit for bit
+        torch.cuda.synchronize(device)
+        host_equal = bool(np.array_equal(c16d.cpu().numpy().view(np.uint16), c16h.view(np.uint16)) and
+                          np.array_equal(prd.cpu().numpy(), prh))
     # pass 2: the same K steps again with every kernel launch bracketed by HIP events on the launch
     # stream -> per-kernel durations for the roofline (the events cost a few % of throughput, which
     # is why they are kept out of pass 1; both wall times are reported)
@@ -177,12 +253,23 @@ def main() -> None:
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"DINOv3 ViT-{args.model[3:].upper()} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
                                f"batch={B}, chunked encode + BiLSTM head (C={BEHAVIORS}, seq_len={SEQ_LEN})",
+                   "input": "uint8 RGB frames resident in HBM before the clock starts; CLS rows and probabilities left in HBM "
+                            "(host-memory-to-host-memory figure: host_path)",
                    "batch": B, "batches_in_flight": args.lanes, "frames_per_gpu": K * B, "frame": [args.hw, args.hw], "parallelism": f"clip-per-gpu x{world}",
                    "weights": "synthetic (seeded counter-based generator)", "operands": "fp16 MFMA, fp32 accumulate/residual; head fp32",
                    "encoder_gflop_per_frame": round(cfg.flops_per_frame(args.hw, args.hw) / 1e9, 3),
                    "head_gflop_per_frame": round(hcfg.flops_per_frame_naive() / 1e9, 4)},
         "end_to_end_tflops": round(value * flops_frame / 1e12, 2),
     }
+    if dt_host is not None:
+        out["host_path"] = {
+            "value": round(frames_total / dt_host, 2), "unit": "frames/s", "ms_per_step": round(dt_host / K * 1e3, 4),
+            "what": "uint8 RGB (n,H,W,3) in pinned host memory -> cbas_fused_push_u8_host (H2D on the copy stream, green "
+                    "picked on the device) -> encoder -> head -> fp16 CLS rows + fp32 probabilities in host memory "
+                    "(SURVEY section 8(d) metric definition); same K steps, PCIe inclusive",
+            "h2d_bytes_per_frame": args.hw * args.hw * 3, "bit_identical_to_hbm_resident_pass": host_equal}
+    if not args.no_gates:
+        out["gates"] = gates(enc, head, args.model, args.hw, args.precision)
     if prof:
         gemm = [k for k in prof if k.endswith("_gemm")]
         g_ms = sum(prof[k]["ms"] for k in gemm)
@@ -192,7 +279,7 @@ def main() -> None:
         out["roofline"] = {
             "bound": "mfma", "kernel": "gemm_f16_8ph_kernel (all epilogues: patch/qkv/o_proj/up/down)",
             "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None, "traffic_source": None,
             "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "launches": g_n,
             "measured": "HIP events around every launch, second pass over the same K steps, one batch in flight",
             "ms_per_step_with_events": round(dt_events / K * 1e3, 4),
@@ -205,6 +292,8 @@ def main() -> None:
         if os.path.exists(pmc):
             try:
                 out["roofline"]["traffic"] = json.load(open(pmc)).get("gemm_f16_hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / "
+                                                     "WRITE_SIZE passes of this command (not measured in this run)")
             except Exception:  # noqa: BLE001
                 pass
     if world == 1 and not args.no_cpu_baseline:

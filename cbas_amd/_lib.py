@@ -49,6 +49,17 @@ SIGNATURES = {
     "cbas_enc_submit_u8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p,
                                    c_void_p, c_void_p]),
     "cbas_enc_wait_stream": (c_int, [c_void_p, c_int, c_void_p]),
+    "cbas_enc_submit_u8_host_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                                            c_void_p, c_void_p, c_void_p]),
+    "cbas_enc_get_config": (c_int, [c_void_p, C.POINTER(EncConfig)]),
+    "cbas_head_get_config": (c_int, [c_void_p, C.POINTER(HeadConfigC)]),
+    "cbas_fused_create": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int64, C.POINTER(c_void_p)]),
+    "cbas_fused_destroy": (None, [c_void_p]),
+    "cbas_fused_reset": (c_int, [c_void_p]),
+    "cbas_fused_push_u8_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64]),
+    "cbas_fused_push_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "cbas_fused_finish": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_void_p), C.POINTER(c_void_p),
+                                  C.POINTER(c_int64), c_void_p]),
     "cbas_enc_set_lanes": (c_int, [c_void_p, c_int]),
     "cbas_enc_set_prune_last_layer": (c_int, [c_void_p, c_int]),
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,

@@ -725,8 +725,11 @@ extern "C" int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64
     return CBAS_OK;
 }
 
-extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
-                                       int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride) {
+// cls_*_dev == nullptr: rows go to the slot's own buffers and on to pinned host memory (cbas_enc_wait);
+// otherwise rows are written to the caller's device buffers and the slot is released by cbas_enc_wait_stream.
+static int submit_u8_host_impl(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height, int width,
+                               int64_t frame_stride, int64_t row_stride, int64_t pixel_stride, float* cls_f32_dev,
+                               f16* cls_f16_dev, bool to_device) {
     int rc = check_frame(h, n, height, width);
     if (rc) return rc;
     if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
@@ -779,18 +782,47 @@ extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* fra
     rc = async_enter(h, lane, ls);
     if (rc) return rc;
     use_lane(h, lane);
-    rc = forward_u8(h, s.in_dev, n, height, width, dev_frame_stride, dev_row_stride, dev_pixel_stride, s.out32_dev,
-                    s.out16_dev, ls, -1, -1);
+    rc = forward_u8(h, s.in_dev, n, height, width, dev_frame_stride, dev_row_stride, dev_pixel_stride,
+                    to_device ? cls_f32_dev : s.out32_dev, to_device ? cls_f16_dev : s.out16_dev, ls, -1, -1);
     use_lane(h, 0);
     if (rc) return rc;
     rc = async_leave(h, lane, ls);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(s.out16_host, s.out16_dev, (int64_t)n * h->D * 2, hipMemcpyDeviceToHost, ls));
-    HIP_TRY(hipMemcpyAsync(s.out32_host, s.out32_dev, (int64_t)n * h->D * 4, hipMemcpyDeviceToHost, ls));
+    if (!to_device) {
+        HIP_TRY(hipMemcpyAsync(s.out16_host, s.out16_dev, (int64_t)n * h->D * 2, hipMemcpyDeviceToHost, ls));
+        HIP_TRY(hipMemcpyAsync(s.out32_host, s.out32_dev, (int64_t)n * h->D * 4, hipMemcpyDeviceToHost, ls));
+    }
     HIP_TRY(hipEventRecord(s.ev_done, ls));
     s.n = n;
     s.busy = true;
-    s.dev_mode = false;
+    s.dev_mode = to_device;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_enc_submit_u8_host(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
+                                       int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride) {
+    return submit_u8_host_impl(h, slot, frames_host, n, height, width, frame_stride, row_stride, pixel_stride, nullptr,
+                               nullptr, false);
+}
+
+extern "C" int cbas_enc_submit_u8_host_dev(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height,
+                                           int width, int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                                           float* cls_f32_dev, uint16_t* cls_f16_dev, void* after_stream) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    if (!cls_f32_dev && !cls_f16_dev) return cbas_fail(CBAS_EINVAL, "no output requested");
+    if (slot >= 0 && slot < CBAS_ENC_SLOTS && !h->slots[slot].busy) {
+        // the output rows may still be read by work queued on after_stream (e.g. the head over an earlier clip)
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipEventRecord(h->slots[slot].ev_in, (hipStream_t)after_stream));
+        HIP_TRY(hipStreamWaitEvent(h->copy, h->slots[slot].ev_in, 0));
+    }
+    return submit_u8_host_impl(h, slot, frames_host, n, height, width, frame_stride, row_stride, pixel_stride,
+                               cls_f32_dev, (f16*)cls_f16_dev, true);
+}
+
+extern "C" int cbas_enc_get_config(const cbas_enc* h, cbas_enc_config* out) {
+    if (!h || !out) return cbas_fail(CBAS_EINVAL, "null argument");
+    *out = h->cfg;
     return CBAS_OK;
 }
 

@@ -1,0 +1,181 @@
+// C-ABI: fused streaming session - encode -> fp16 CLS -> sliding-window head without the CLS rows leaving
+// HBM ("cbas_fused_run").  The reference does this as two threads with a file in
+// between (EncodeThread writes _cls.h5, ClassificationThread reads it back: backend/workthreads.py:316-328,
+// :488-498; cbas.py:423-440 chunk loop, :497-551 window loop); the numerical contract is unchanged because
+// the head still consumes the CLS rows AFTER their round-to-fp16 (what the file would have held).
+//
+// Built only on the public entry points of the encoder and the head (no access to their internals): batches
+// alternate over the encoder's slots / compute lanes, a segment of frames is classified as soon as its
+// right-hand context (seq_len/2 rows) has been encoded by batches the session's stream is already ordered
+// after, in groups of `classify_every` frames, so the head never drains the encoder lanes mid-clip.
+#include <new>
+
+#include "api_common.h"
+
+struct cbas_fused {
+    cbas_enc* enc;
+    cbas_head* head;
+    int device;
+    int D, C, half, max_batch;
+    int64_t capacity, classify_every;
+    float temperature;
+    uint16_t* cls16 = nullptr;      // [capacity][D] IEEE half, device
+    float* probs = nullptr;         // [capacity][C], device
+    hipStream_t st = nullptr;       // the head runs here; encoder batches are chained to it by events
+    int64_t encoded = 0, classified = 0, landed = 0;
+    struct Busy { int64_t n = 0; uint64_t seq = 0; } busy[CBAS_ENC_SLOTS];
+    int next_slot = 0;
+    uint64_t seq = 0;
+};
+
+namespace {
+
+// order the session's stream after the oldest batches still in flight, oldest first
+int drain(cbas_fused* f) {
+    for (;;) {
+        int best = -1;
+        for (int s = 0; s < CBAS_ENC_SLOTS; ++s)
+            if (f->busy[s].n && (best < 0 || f->busy[s].seq < f->busy[best].seq)) best = s;
+        if (best < 0) return CBAS_OK;
+        int rc = cbas_enc_wait_stream(f->enc, best, f->st);
+        if (rc) return rc;
+        f->landed += f->busy[best].n;
+        f->busy[best].n = 0;
+    }
+}
+
+int classify(cbas_fused* f, int64_t count, int64_t n_rows) {
+    int rc = cbas_head_infer_f16_range(f->head, f->cls16, n_rows, f->classified, count, f->temperature,
+                                       f->probs + f->classified * f->C, nullptr, f->st);
+    if (rc) return rc;
+    f->classified += count;
+    return CBAS_OK;
+}
+
+int push(cbas_fused* f, const uint8_t* frames, bool host, int n, int height, int width, int64_t frame_stride,
+         int64_t row_stride, int64_t pixel_stride, void* after_stream) {
+    if (!f) return cbas_fail(CBAS_EINVAL, "null session");
+    if (n <= 0) return cbas_fail(CBAS_EINVAL, "n=%d", n);
+    if (f->encoded + n > f->capacity)
+        return cbas_fail(CBAS_EINVAL, "session capacity %lld exceeded (%lld encoded + %d)", (long long)f->capacity,
+                         (long long)f->encoded, n);
+    HIP_TRY(hipSetDevice(f->device));
+    for (int i = 0; i < n; i += f->max_batch) {
+        const int m = n - i < f->max_batch ? n - i : f->max_batch;
+        const int slot = f->next_slot;
+        f->next_slot = (f->next_slot + 1) % CBAS_ENC_SLOTS;
+        if (f->busy[slot].n) {                           // slots are recycled in submission order
+            int rc = cbas_enc_wait_stream(f->enc, slot, f->st);
+            if (rc) return rc;
+            f->landed += f->busy[slot].n;
+            f->busy[slot].n = 0;
+        }
+        uint16_t* rows = f->cls16 + f->encoded * f->D;
+        const uint8_t* src = frames + (int64_t)i * frame_stride;
+        int rc = host ? cbas_enc_submit_u8_host_dev(f->enc, slot, src, m, height, width, frame_stride, row_stride,
+                                                    pixel_stride, nullptr, rows, f->st)
+                      : cbas_enc_submit_u8(f->enc, slot, src, m, height, width, frame_stride, row_stride, pixel_stride,
+                                           nullptr, rows, after_stream);
+        if (rc) return rc;
+        f->busy[slot].n = m;
+        f->busy[slot].seq = ++f->seq;
+        f->encoded += m;
+    }
+    const int64_t ready = f->landed - f->half - f->classified;       // frames with their full right context
+    if (ready >= f->classify_every) return classify(f, ready, f->landed);
+    return CBAS_OK;
+}
+
+}  // namespace
+
+extern "C" int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacity_frames, float temperature,
+                                 int64_t classify_every, cbas_fused** out) {
+    if (!enc || !head || !out) return cbas_fail(CBAS_EINVAL, "null argument");
+    *out = nullptr;
+    cbas_enc_config ec;
+    cbas_head_config hc;
+    int rc = cbas_enc_get_config(enc, &ec);
+    if (rc) return rc;
+    rc = cbas_head_get_config(head, &hc);
+    if (rc) return rc;
+    if (hc.in_features != ec.hidden_size)
+        return cbas_fail(CBAS_EINVAL, "head expects %d features, the encoder emits %d", hc.in_features, ec.hidden_size);
+    if (capacity_frames <= 0) return cbas_fail(CBAS_EINVAL, "capacity_frames=%lld", (long long)capacity_frames);
+    cbas_fused* f = new (std::nothrow) cbas_fused();
+    if (!f) return cbas_fail(CBAS_ENOMEM, "out of host memory");
+    f->enc = enc; f->head = head;
+    f->D = ec.hidden_size; f->C = hc.out_features; f->half = hc.seq_len / 2; f->max_batch = ec.max_batch;
+    f->capacity = capacity_frames; f->temperature = temperature;
+    f->classify_every = classify_every > 0 ? classify_every : 1024;
+    hipError_t e = hipGetDevice(&f->device);
+    if (e == hipSuccess) e = hipMalloc(&f->cls16, (size_t)capacity_frames * f->D * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(&f->probs, (size_t)capacity_frames * f->C * sizeof(float));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        cbas_fail(e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP, "cbas_fused_create: %s", hipGetErrorString(e));
+        cbas_fused_destroy(f);
+        return e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP;
+    }
+    *out = f;
+    return CBAS_OK;
+}
+
+extern "C" void cbas_fused_destroy(cbas_fused* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)drain(f);
+    if (f->st) { (void)hipStreamSynchronize(f->st); (void)hipStreamDestroy(f->st); }
+    if (f->cls16) (void)hipFree(f->cls16);
+    if (f->probs) (void)hipFree(f->probs);
+    delete f;
+}
+
+extern "C" int cbas_fused_reset(cbas_fused* f) {
+    if (!f) return cbas_fail(CBAS_EINVAL, "null session");
+    HIP_TRY(hipSetDevice(f->device));
+    int rc = drain(f);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(f->st));       // the previous clip's rows are about to be overwritten
+    f->encoded = f->classified = f->landed = 0;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_fused_push_u8_host(cbas_fused* f, const uint8_t* frames_host, int n, int height, int width,
+                                       int64_t frame_stride, int64_t row_stride, int64_t pixel_stride) {
+    return push(f, frames_host, true, n, height, width, frame_stride, row_stride, pixel_stride, nullptr);
+}
+
+extern "C" int cbas_fused_push_u8(cbas_fused* f, const uint8_t* frames_dev, int n, int height, int width,
+                                  int64_t frame_stride, int64_t row_stride, int64_t pixel_stride, void* after_stream) {
+    return push(f, frames_dev, false, n, height, width, frame_stride, row_stride, pixel_stride, after_stream);
+}
+
+extern "C" int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev,
+                                 const float** probs_dev, int64_t* n_frames, void* stream) {
+    if (!f) return cbas_fail(CBAS_EINVAL, "null session");
+    HIP_TRY(hipSetDevice(f->device));
+    int rc = drain(f);
+    if (rc) return rc;
+    if (f->encoded > f->classified) {
+        rc = classify(f, f->encoded - f->classified, f->encoded);      // the clip's right edge replicates its last row
+        if (rc) return rc;
+    }
+    if (cls_f16_host)
+        HIP_TRY(hipMemcpyAsync(cls_f16_host, f->cls16, (size_t)f->encoded * f->D * 2, hipMemcpyDeviceToHost, f->st));
+    if (probs_host)
+        HIP_TRY(hipMemcpyAsync(probs_host, f->probs, (size_t)f->encoded * f->C * 4, hipMemcpyDeviceToHost, f->st));
+    if (cls_f16_dev) *cls_f16_dev = f->cls16;
+    if (probs_dev) *probs_dev = f->probs;
+    if (n_frames) *n_frames = f->encoded;
+    if (cls_f16_host || probs_host || !stream) {
+        HIP_TRY(hipStreamSynchronize(f->st));                           // host results are complete at return
+    }
+    if (stream) {                                                       // device results: `stream` waits, the host does not
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, f->st));
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+        HIP_TRY(hipEventDestroy(ev));
+    }
+    return CBAS_OK;
+}

@@ -77,6 +77,12 @@ int project(cbas_head* h, const float* rows32, int64_t n_rows, hipStream_t st) {
 
 extern "C" int64_t cbas_head_weights_count(const cbas_head_config* cfg) { return cfg ? head_weights_count(*cfg) : -1; }
 
+extern "C" int cbas_head_get_config(const cbas_head* h, cbas_head_config* out) {
+    if (!h || !out) return cbas_fail(CBAS_EINVAL, "null argument");
+    *out = h->cfg;
+    return CBAS_OK;
+}
+
 extern "C" void cbas_head_destroy(cbas_head* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);

@@ -4,17 +4,29 @@ ClassificationThread reads it back: backend/workthreads.py:316-328, 488-498) col
 pass for live inference; the numerical contract is unchanged because the head still consumes the
 CLS rows *after* their round-to-fp16 (what the file would have held).
 
-A segment of frames is classified as soon as its right-hand context (``seq_len // 2`` rows) has
-been encoded, in groups of ``classify_every`` frames so the head kernels launch with full grids.
+The session itself lives behind the C ABI (``cbas_fused_*`` in include/cbas_mi355x.h, csrc/api_fused.hip):
+slot rotation over the encoder's compute lanes, the "classify what has landed" rule and the clip buffers are
+native; this class is the torch-tensor view of it.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes as C
+from typing import Tuple
 
+import numpy as np
 import torch
 
+from . import _lib
 from .encoder import DinoEncoder
 from .head import ClassifierLSTMDeltas
+
+
+def _layout(frames, channel: int):
+    if frames.ndim == 4:
+        n, H, W, Cn = frames.shape
+        return n, H, W, (H * W * Cn, W * Cn, Cn), channel
+    n, H, W = frames.shape
+    return n, H, W, (H * W, W, 1), 0
 
 
 class ClipStream:
@@ -24,72 +36,83 @@ class ClipStream:
         self.capacity = int(capacity)
         self.temperature = float(temperature)
         self.classify_every = int(classify_every)
-        dev = encoder.device
-        self.cls16 = torch.empty((self.capacity, encoder.config.hidden_size), dtype=torch.float16, device=dev)
-        self.probs = torch.empty((self.capacity, head.out_features), dtype=torch.float32, device=dev)
-        self.half = head.seq_len // 2
-        self.reset()
+        head.to(encoder.device)
+        head._ensure()
+        self._lib = _lib.load()
+        self._keep = []              # frames of the open clip (device pushes must stay valid until finish)
+        h = C.c_void_p()
+        with torch.cuda.device(encoder.device):
+            _lib.check(self._lib.cbas_fused_create(encoder._h, head._h, self.capacity, self.temperature,
+                                                   self.classify_every, C.byref(h)), "cbas_fused_create")
+        self._h = h
+        self.encoded = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.cbas_fused_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def reset(self) -> None:
-        self._drain()
+        _lib.check(self._lib.cbas_fused_reset(self._h), "cbas_fused_reset")
+        self._keep = []
         self.encoded = 0
-        self.classified = 0
-        self.landed = 0          # rows whose batches the current stream is already ordered after
-
-    def _drain(self) -> None:
-        """Order the current stream after every batch still in flight on the encoder's compute lanes."""
-        busy = getattr(self, "_busy", {})
-        for slot in sorted(busy, key=lambda s: busy[s][1]):          # submission order
-            self.enc.wait_stream(slot)
-            self.landed += busy[slot][2]
-        self._busy = {}
 
     def push_u8(self, frames: torch.Tensor, channel: int = 1) -> None:
-        """Encode one batch of uint8 frames resident in HBM ((n,H,W,3) or (n,H,W)) and classify every
-        frame whose window is now complete."""
-        n = frames.shape[0]
-        if self.encoded + n > self.capacity:
-            raise RuntimeError(f"ClipStream capacity {self.capacity} exceeded")
-        self._encode_into(frames, channel, self.cls16[self.encoded:self.encoded + n])
-        self.encoded += n
-        # The head only consumes rows the current stream is ALREADY ordered after (batches whose slot has been
-        # recycled): classifying never waits for the batches in flight, so the encoder lanes are not drained
-        # in the middle of a clip.  It therefore trails the encoder by up to ENC_SLOTS batches + the half window.
-        ready = self.landed - self.half - self.classified            # frames with full right context
-        if ready >= self.classify_every:
-            self._classify(ready, self.landed)
-
-    def _encode_into(self, frames: torch.Tensor, channel: int, out16: torch.Tensor) -> None:
-        from . import _lib
-        enc = self.enc
-        if frames.dim() == 4:
-            n, H, W, Cn = frames.shape
-            strides, off = (H * W * Cn, W * Cn, Cn), channel
-        else:
-            n, H, W = frames.shape
-            strides, off = (H * W, W, 1), 0
-        # asynchronous submissions on the encoder's two compute lanes: consecutive batches overlap
+        """Append uint8 frames resident in HBM ((n,H,W,3) or (n,H,W)); classifies every frame whose window is
+        complete among the batches that have already landed."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda
         frames = frames.contiguous()
-        for i in range(0, n, enc.max_batch):
-            m = min(enc.max_batch, n - i)
-            slot = self._next_slot = (getattr(self, "_next_slot", -1) + 1) % _lib.ENC_SLOTS
-            if slot in self._busy:
-                enc.wait_stream(slot)                   # batches are recycled in submission order
-                self.landed += self._busy.pop(slot)[2]
-            sub = frames[i:i + m]
-            enc.submit_dev(slot, sub, out16[i:i + m], None, channel)
-            self._seq = getattr(self, "_seq", 0) + 1
-            self._busy[slot] = (sub, self._seq, m)      # keeps the frames alive until the slot is waited for
+        n, H, W, strides, off = _layout(frames, channel)
+        stream = torch.cuda.current_stream(self.enc.device).cuda_stream
+        _lib.check(self._lib.cbas_fused_push_u8(self._h, frames.data_ptr() + off, n, H, W, *strides, stream),
+                   "cbas_fused_push_u8")
+        self._keep.append(frames)
+        self.encoded += n
 
-    def _classify(self, count: int, n_rows: int) -> None:
-        """Classify frames [classified, classified + count) of the first ``n_rows`` rows (all landed)."""
-        self.head.infer_range_into(self.cls16, n_rows, self.classified, count, self.probs, self.temperature)
-        self.classified += count
+    def push_host(self, frames: np.ndarray, channel: int = 1) -> None:
+        """Append uint8 frames from host memory (numpy (n,H,W,3) or (n,H,W), C-contiguous).  Pinned arrays
+        (e.g. ``torch.Tensor.pin_memory().numpy()``) are DMA'd directly and must stay untouched until finish."""
+        assert frames.dtype == np.uint8 and frames.flags.c_contiguous
+        n, H, W, strides, off = _layout(frames, channel)
+        _lib.check(self._lib.cbas_fused_push_u8_host(self._h, frames.ctypes.data + off, n, H, W, *strides),
+                   "cbas_fused_push_u8_host")
+        self._keep.append(frames)
+        self.encoded += n
+
+    def _views(self, p16, pp, n):
+        D, Cn = self.enc.config.hidden_size, self.head.out_features
+        dev = self.enc.device
+
+        def view(ptr, rows, cols, dtype, itemsize):
+            if rows == 0:
+                return torch.empty((0, cols), dtype=dtype, device=dev)
+            iface = {"shape": (rows, cols), "typestr": "<f%d" % itemsize, "data": (ptr, False), "version": 2}
+            holder = type("_Dev", (), {"__cuda_array_interface__": iface})()
+            return torch.as_tensor(holder, device=dev)
+        return view(p16.value, n, D, torch.float16, 2), view(pp.value, n, Cn, torch.float32, 4)
 
     def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Classify the tail (the clip's right edge replicates its last row) and return
-        (cls_f16 (N,D), probs (N,C)) views on the device."""
-        self._drain()
-        if self.encoded > self.classified:
-            self._classify(self.encoded - self.classified, self.encoded)
-        return self.cls16[:self.encoded], self.probs[:self.encoded]
+        """Classify the tail and return (cls_f16 (N,D), probs (N,C)) views of the session's device buffers,
+        ordered on the current torch stream (valid until the next reset / push)."""
+        p16, pp, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        stream = torch.cuda.current_stream(self.enc.device).cuda_stream
+        _lib.check(self._lib.cbas_fused_finish(self._h, None, None, C.byref(p16), C.byref(pp), C.byref(n), stream),
+                   "cbas_fused_finish")
+        return self._views(p16, pp, int(n.value))
+
+    def finish_host(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Classify the tail and copy the clip out: (cls_f16 (N,D) float16, probs (N,C) float32) numpy arrays."""
+        D, Cn = self.enc.config.hidden_size, self.head.out_features
+        o16 = np.empty((self.encoded, D), np.float16)
+        opr = np.empty((self.encoded, Cn), np.float32)
+        n = C.c_int64(0)
+        _lib.check(self._lib.cbas_fused_finish(self._h, o16.ctypes.data, opr.ctypes.data, None, None, C.byref(n), None),
+                   "cbas_fused_finish")
+        assert int(n.value) == self.encoded
+        return o16, opr

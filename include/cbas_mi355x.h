@@ -19,6 +19,8 @@
  *   cbas_head_forward_windows              backend/classifier_head.py:150-172 ClassifierLSTMDeltas.forward
  *   cbas_head_infer_f16                    backend/cbas.py:497-551   the window loop of infer_file
  *                                          (edge replicate padding, head, softmax(logits/max(1e-3,T)))
+ *   cbas_fused_*                           backend/workthreads.py:316-328 + 488-498: EncodeThread -> _cls.h5 ->
+ *                                          ClassificationThread, as one streaming session (rows stay in HBM)
  *   cbas_last_error                        Python exceptions raised on those paths
  *
  * Conventions
@@ -130,6 +132,14 @@ int cbas_enc_submit_u8(cbas_enc* h, int slot, const uint8_t* frames_dev, int n, 
                        int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
                        float* cls_f32_dev, uint16_t* cls_f16_dev, void* after_stream);
 int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream);
+/* Host frames in, device rows out: cbas_enc_submit_u8_host's ingest (pinned staging or direct DMA, copy stream)
+ * with cbas_enc_submit_u8's outputs (rows written to cls_*_dev, slot released by cbas_enc_wait_stream).  The
+ * batch is ordered after everything queued so far on `after_stream` (which may still read those rows). */
+int cbas_enc_submit_u8_host_dev(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height, int width,
+                                int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
+                                float* cls_f32_dev, uint16_t* cls_f16_dev, void* after_stream);
+/* The configuration the handle was created with. */
+int cbas_enc_get_config(const cbas_enc* h, cbas_enc_config* out);
 /* Use 1 or 2 compute lanes for the asynchronous forms (2 by default; 1 serialises the batches, e.g. to time
  * kernels without another batch's kernels running beside them).  No batch may be in flight. */
 int cbas_enc_set_lanes(cbas_enc* h, int n_lanes);
@@ -214,6 +224,38 @@ int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_fra
 int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, int64_t first,
                               int64_t count, float temperature, float* probs_dev, float* logits_dev,
                               void* stream);
+
+int cbas_head_get_config(const cbas_head* h, cbas_head_config* out);
+
+/* ---- fused streaming session: encode -> fp16 CLS -> head, rows never leave HBM ---------------------
+ * The reference runs the two halves as two threads with a file in between (EncodeThread -> _cls.h5 ->
+ * ClassificationThread: backend/workthreads.py:316-328, 488-498; chunk loop backend/cbas.py:423-440, window
+ * loop :497-551).  A session owns a device clip buffer of `capacity_frames` rows (fp16 CLS + fp32
+ * probabilities) and a stream for the head; pushes queue batches of <= max_batch frames on the encoder's
+ * slots / compute lanes (splitting larger pushes), and every `classify_every` frames whose +-seq_len/2
+ * context has been encoded are classified (windows clamp at the clip's ends exactly as infer_file's
+ * replicate padding does).  Results are identical to cbas_enc_forward_u8 + cbas_head_infer_f16 over the
+ * whole clip, bit for bit.  The encoder and head handles must outlive the session and must not be driven
+ * through their own asynchronous entry points while a clip is open. */
+typedef struct cbas_fused cbas_fused;
+int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacity_frames, float temperature,
+                      int64_t classify_every /* 0: 1024 */, cbas_fused** out);
+void cbas_fused_destroy(cbas_fused* f);
+/* Start a new clip (waits for the previous clip's device work). */
+int cbas_fused_reset(cbas_fused* f);
+/* Append n frames from host memory (same layout / pinned-memory rules as cbas_enc_submit_u8_host). */
+int cbas_fused_push_u8_host(cbas_fused* f, const uint8_t* frames_host, int n, int height, int width,
+                            int64_t frame_stride, int64_t row_stride, int64_t pixel_stride);
+/* Append n frames already in HBM, ready once everything queued on `after_stream` has run; they must stay
+ * valid until the clip is finished. */
+int cbas_fused_push_u8(cbas_fused* f, const uint8_t* frames_dev, int n, int height, int width,
+                       int64_t frame_stride, int64_t row_stride, int64_t pixel_stride, void* after_stream);
+/* Classify the tail and hand out the clip: any of cls_f16_host (N x D halves), probs_host (N x C floats) are
+ * filled (the call then blocks until they are complete); cls_f16_dev / probs_dev receive the session's device
+ * buffers (valid until the next reset / push) and, when `stream` is not NULL, that stream is made to wait for
+ * them instead of the host.  n_frames receives N. */
+int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev,
+                      const float** probs_dev, int64_t* n_frames, void* stream);
 
 /* ---- head training -------------------------------------------------------------------------
  * Replaces the optimisation step inside train_lstm_model (backend/cbas.py:1326-1348):

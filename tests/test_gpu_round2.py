@@ -189,3 +189,52 @@ def test_infer_file_follows_weight_updates_of_a_reference_module(tmp_path):
         m.lin1.bias.add_(0.5)
     w3 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
     np.testing.assert_allclose(run(m), PO.classify_cls(cls, w3, 31, 1.0), atol=1e-4)
+
+
+def test_fused_session_host_and_device_pushes_equal_two_step_path():
+    """cbas_fused_* (encode -> head with the rows resident in HBM) == cbas_enc_forward_u8 over the clip followed by
+    cbas_head_infer_f16 over the rows, bit for bit: ragged pushes larger and smaller than max_batch, host (pageable
+    and pinned) and device frames, several clips through one session, capacity overflow is an error."""
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from cbas_amd.stream import ClipStream
+    cfg, enc = _enc("tiny", 16, (64, 64))
+    hcfg = C.HeadConfig(in_features=cfg.hidden_size, out_features=5, seq_len=31)
+    head = ClassifierLSTMDeltas(cfg.hidden_size, 5, seq_len=31)
+    head.load_state_dict(W.synth_head_weights(hcfg, 7))
+    head.to("cuda")
+    try:
+        frames = synth.cage_frames(51, 331, 64, 64)
+        fd = torch.from_numpy(frames).cuda()
+        ref16, _ = enc.encode_u8(fd, want_f32=False)
+        refp = head.infer_clip(ref16, 0.8)
+        torch.cuda.synchronize()
+        st = ClipStream(enc, head, capacity=400, temperature=0.8, classify_every=48)
+        pinned = torch.from_numpy(frames).pin_memory().numpy()
+        for src in ("dev", "host", "pinned", "dev"):
+            st.reset()
+            o = 0
+            for n in (16, 40, 3, 100, 16, 1, 155):             # 331 frames
+                if src == "dev":
+                    st.push_u8(fd[o:o + n])
+                else:
+                    st.push_host((frames if src == "host" else pinned)[o:o + n])
+                o += n
+            if src == "dev":
+                c16, pr = st.finish()
+                torch.cuda.synchronize()
+                assert torch.equal(c16, ref16) and torch.equal(pr, refp), src
+            else:
+                c16, pr = st.finish_host()
+                assert np.array_equal(c16.view(np.uint16), ref16.cpu().numpy().view(np.uint16)), src
+                assert np.array_equal(pr, refp.cpu().numpy()), src
+        st.reset()
+        st.push_u8(fd[:300])
+        with pytest.raises(RuntimeError, match="capacity"):
+            st.push_u8(fd[:101])
+        c16, pr = st.finish()
+        torch.cuda.synchronize()
+        assert c16.shape[0] == 300 and torch.equal(c16, ref16[:300])
+        st.close()
+    finally:
+        head.close()
+        enc.close()

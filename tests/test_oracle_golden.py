@@ -141,3 +141,18 @@ def test_e2e_config1_golden(golden_dir):
     np.testing.assert_allclose(probs_g, g["probs"], atol=1e-5)
     assert (probs_g.argmax(1) == g["labels"]).all()
     assert (probs.argmax(1) == g["labels"]).all()
+
+
+@pytest.mark.parametrize("name,cfgname,hw", [("vitb16_224_noise", "vitb16", 224), ("vitb16_256", "vitb16", 256)])
+def test_torch_restatement_against_reference_goldens(golden_dir, name, cfgname, hw):
+    """oracle/vit_oracle_torch.py (what bench.py times as cpu_baseline) against CLS rows made by the reference."""
+    from oracle import vit_oracle_torch as VT
+    g = load(golden_dir, name)
+    cfg = C.NAMED_VIT[cfgname]
+    w = VT.to_torch(W.synth_encoder_weights(cfg, 1234))
+    n = int(g["n"])
+    mk = synth.noise_frames if str(g["kind"]) == "noise" else synth.cage_frames
+    fr = mk(int(g["frame_seed"]), n, hw, hw)
+    cls = VT.encode_frames(fr, w, cfg, batch=4)
+    rel = np.linalg.norm(cls - g["cls"], axis=1) / np.linalg.norm(g["cls"], axis=1)
+    assert rel.max() < 1e-5, rel.max()
