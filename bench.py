@@ -121,7 +121,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--precision", type=int, default=0)
-    ap.add_argument("--cpu-frames", type=int, default=256)
+    ap.add_argument("--cpu-frames", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
@@ -289,7 +289,8 @@ def main() -> None:
                               "share": round(v["ms"] * 1e-3 / dt_events, 4)} for k, v in prof.items()},
         }
         pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # the committed PMC passes were taken on the headline workload only; other workloads report null
+        if os.path.exists(pmc) and (args.model, args.hw, B, args.precision) == ("vitb16", 224, 64, 0):
             try:
                 out["roofline"]["traffic"] = json.load(open(pmc)).get("gemm_f16_hbm_bytes_per_launch")
                 out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / "

@@ -45,6 +45,7 @@ struct Slot {
     hipEvent_t ev_copied = nullptr, ev_done = nullptr, ev_in = nullptr;
     int n = 0;
     bool busy = false;
+    bool used = false;            // ev_copied / ev_done have been recorded at least once
     bool dev_mode = false;        // submitted by cbas_enc_submit_u8 (device in/out) rather than ..._host
 };
 
@@ -742,6 +743,12 @@ static int submit_u8_host_impl(cbas_enc* h, int slot, const uint8_t* frames_host
     // Bytes of the caller's layout are shipped AS THEY ARE (for decord's (n,H,W,3) RGB: 3 bytes per pixel, trivial on
     // PCIe 5) and the consumed channel is picked by the ingest kernel through the strides, so the host does no
     // per-pixel work.  `ext` = bytes from a frame's first consumed pixel to its last.
+    if (s.used) {
+        // A slot released by cbas_enc_wait_stream was never waited for on the HOST: its previous H2D copy may still be
+        // reading the pinned staging, and its previous batch may still be reading in_dev.
+        HIP_TRY(hipEventSynchronize(s.ev_copied));
+        HIP_TRY(hipStreamWaitEvent(h->copy, s.ev_done, 0));
+    }
     const int64_t ext = (int64_t)(height - 1) * row_stride + (int64_t)(width - 1) * pixel_stride + 1;
     const bool dense = n == 1 || frame_stride >= ext;               // frames do not interleave
     int64_t dev_frame_stride = plane, dev_row_stride = width, dev_pixel_stride = 1, bytes = (int64_t)n * plane;
@@ -795,6 +802,7 @@ static int submit_u8_host_impl(cbas_enc* h, int slot, const uint8_t* frames_host
     HIP_TRY(hipEventRecord(s.ev_done, ls));
     s.n = n;
     s.busy = true;
+    s.used = true;
     s.dev_mode = to_device;
     return CBAS_OK;
 }

@@ -47,4 +47,23 @@ static __device__ __forceinline__ float gelu_fast(float x) {
     return x * (x >= 0.f ? 1.0f - hq : hq);
 }
 
+// ---- MX-fp8 (OCP e4m3 elements, E8M0 scale per 32-element block) -------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// E8M0 byte of the smallest power-of-two scale s with amax / s <= 448 (the largest e4m3 value): no element clips.
+// amax = 1.f * 2^(E-127); 448 = 1.75 * 2^8  =>  byte = E - 8 (+1 when the fraction exceeds .75), clamped to [0, 253].
+static __device__ __forceinline__ int mx_scale_byte(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    int b = (int)((u >> 23) & 0xffu) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
+    return b < 0 ? 0 : (b > 253 ? 253 : b);
+}
+// 2^-(byte-127): what the elements are multiplied by before the e4m3 conversion
+static __device__ __forceinline__ float mx_inv_scale(int byte) { return __uint_as_float((unsigned)(254 - byte) << 23); }
+// four floats -> four e4m3 bytes (round to nearest even; |v| <= 448 by construction)
+static __device__ __forceinline__ unsigned cvt4_e4m3(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -11,6 +11,7 @@ enum GemmEpilogue {
     EPI_QKV   = 1,   // + bias, RoPE on patch rows of q and k, q *= 1/8              (fp16 out)
     EPI_RESID = 2,   // x[m][n] += (acc + bias[n]) * lambda[n]                        (fp32 in/out)
     EPI_GELU  = 3,   // u[m][n] = gelu_erf(acc + bias[n])                             (fp16 out)
+    EPI_GELU_F8 = 4, // the same, stored as MX-fp8: e4m3 bytes + one E8M0 scale per 32 columns (precision 2)
 };
 
 enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2, GEMM_TILE_128x256 = 3,
@@ -28,6 +29,17 @@ struct GemmParams {
     int lda;             // row stride of A in elements (0: K).  lda = T*D reads one row per frame (the CLS rows)
     const f16* W;        // [N][K]  (hi part when split)
     const f16* W_lo;     // [N][K]  residual W - fp16(W) as fp16, or nullptr
+    // MX-fp8 operands (precision 2; gemm_f16_8ph.hip only): e4m3 bytes, K contiguous, plus E8M0 block scales, one
+    // byte per 32 k-elements, stored K-tile-major as dwords: sc[(k / 128) * ld + row] byte (k % 128) / 32.
+    // A8 != nullptr selects the fp8 kernel (A / W above are then unused).
+    const uint8_t* A8;   // [M_pad][lda]
+    const uint8_t* W8;   // [N][K]
+    const uint32_t* A_sc;   // [K/128][sc_lda]
+    const uint32_t* W_sc;   // [K/128][N]
+    int sc_lda;
+    uint8_t* out_f8;     // EPI_GELU_F8: [M][ldo] bytes
+    uint32_t* out_sc;    // EPI_GELU_F8: [N/128][sc_ldo]
+    int sc_ldo;
     int M;               // valid rows (stores are skipped for rows >= M)
     int M_pad;           // rows allocated in A (loads of rows >= M_pad are clamped)
     int N;               // multiple of 128
@@ -69,6 +81,9 @@ int launch_im2col_f32(const float* frames, int n, int height, int width, f16* A,
 // ldx = row stride of x in elements (D for the whole residual stream, T*D for the CLS rows only)
 int launch_layernorm_f16(const float* x, int64_t ldx, const float* gamma, const float* beta, f16* out, int M, int D,
                          float eps, hipStream_t stream);
+// the same with an MX-fp8 result: out8 [M][D] e4m3 bytes, out_sc [D/128][sc_ld] block scales (GemmParams::A_sc layout)
+int launch_layernorm_f8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* out8,
+                        uint32_t* out_sc, int sc_ld, int M, int D, float eps, hipStream_t stream);
 // Final LayerNorm on the CLS row of every frame: x[b*T] -> cls_f32[b][D] / cls_f16[b][D]
 int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
                           f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream);
@@ -76,12 +91,16 @@ int launch_final_norm_cls(const float* x, const float* gamma, const float* beta,
 // Multi-head attention over frames: qkv16 [n*T][3D] (q pre-scaled by 1/8, RoPE applied) -> o16 [n*T][D]
 // q_cls != nullptr: only the CLS query of every frame (the last layer: [tf]:540-541 + cbas.py:677 consume row 0
 // alone): q_cls [n][D] holds the projected CLS queries, out is then [n][D]; K and V still come from qkv.
-int launch_attention(const f16* qkv, const f16* q_cls, f16* out, int n, int T, int D, int n_heads, hipStream_t stream);
+// out_sc != nullptr: the context is stored as MX-fp8 (out = e4m3 bytes [n*T][D], out_sc [D/128][sc_ld] scales)
+int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_sc, int sc_ld, int n, int T, int D,
+                     int n_heads, hipStream_t stream);
 
 // fp32 -> fp16 weight conversion (optionally also the fp16 residual), n elements
 int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t stream);
 // patch weight (D,3,16,16) fp32 -> sum over the 3 identical input channels -> (D,256) fp16 hi (+lo),
 // and the same duplicated along K as (D,512) for the float-input path
+// fp32 weight [N][K] -> MX-fp8: e4m3 bytes [N][K] + block scales [K/128][N] (GemmParams::W_sc layout); K % 128 == 0
+int launch_pack_fp8_weight(const float* src, uint8_t* w8, uint32_t* sc, int N, int K, hipStream_t stream);
 int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, int ps, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -146,8 +146,8 @@ class _RefLikeHead(torch.nn.Module):
         super().__init__()
         nn = torch.nn
         self.in_features, self.out_features, self.seq_len, self.sw, self.ema_alpha = I, Cn, T, 5, 0.3
-        self.gate = nn.Parameter(torch.zeros(1))
-        self.attention_temp = nn.Parameter(torch.zeros(1))
+        self.gate = nn.Parameter(torch.zeros(()))
+        self.attention_temp = nn.Parameter(torch.zeros(()))
         for s in ("cls", "delta", "acc"):
             setattr(self, f"{s}_bottleneck", nn.Sequential(nn.Linear(I, 128)))
             setattr(self, f"{s}_ln", nn.LayerNorm(128))
