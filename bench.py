@@ -44,6 +44,7 @@ from cbas_amd import synth  # noqa: E402
 
 METRIC = "frames/sec DINOv3-B/16 224px encode+LSTM classify, 1/2/4/8 MI355X"     # BASELINE.json "metric", verbatim
 MFMA_F16_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0      # dense fp8 (block-scaled) MFMA peak, same guide
 BEHAVIORS = 9
 SEQ_LEN = 31
 
@@ -250,13 +251,15 @@ def main() -> None:
     out = {
         "metric": METRIC, "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
+        "dtype": "fp8" if args.precision == 2 else "f16", "data": "synthetic",
         "config": {"workload": f"DINOv3 ViT-{args.model[3:].upper()} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
                                f"batch={B}, chunked encode + BiLSTM head (C={BEHAVIORS}, seq_len={SEQ_LEN})",
                    "input": "uint8 RGB frames resident in HBM before the clock starts; CLS rows and probabilities left in HBM "
                             "(host-memory-to-host-memory figure: host_path)",
                    "batch": B, "batches_in_flight": args.lanes, "frames_per_gpu": K * B, "frame": [args.hw, args.hw], "parallelism": f"clip-per-gpu x{world}",
-                   "weights": "synthetic (seeded counter-based generator)", "operands": "fp16 MFMA, fp32 accumulate/residual; head fp32",
+                   "weights": "synthetic (seeded counter-based generator)", "operands": ("MX-fp8 (e4m3 + E8M0 block-32 scales) MFMA for qkv/o_proj/up/down, fp16 attention/patch/CLS tail, "
+                                "fp32 accumulate/residual; head fp32") if args.precision == 2 else
+                               "fp16 MFMA, fp32 accumulate/residual; head fp32",
                    "encoder_gflop_per_frame": round(cfg.flops_per_frame(args.hw, args.hw) / 1e9, 3),
                    "head_gflop_per_frame": round(hcfg.flops_per_frame_naive() / 1e9, 4)},
         "end_to_end_tflops": round(value * flops_frame / 1e12, 2),
@@ -276,10 +279,12 @@ def main() -> None:
         g_fl = sum(prof[k]["flops"] for k in gemm)
         g_n = sum(prof[k]["launches"] for k in gemm)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
+        peak = MFMA_FP8_PEAK_TFLOPS if args.precision == 2 else MFMA_F16_PEAK_TFLOPS
         out["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_f16_8ph_kernel (all epilogues: patch/qkv/o_proj/up/down)",
-            "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None, "traffic_source": None,
+            "bound": "mfma", "kernel": "gemm_f16_8ph_kernel (all epilogues: patch/qkv/o_proj/up/down)" +
+                                       (", MX-fp8 form (F8 = true)" if args.precision == 2 else ""),
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
             "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "launches": g_n,
             "measured": "HIP events around every launch, second pass over the same K steps, one batch in flight",
             "ms_per_step_with_events": round(dt_events / K * 1e3, 4),

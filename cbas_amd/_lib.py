@@ -67,6 +67,8 @@ SIGNATURES = {
     "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
     "cbas_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float),
                                       C.POINTER(C.c_ulonglong)]),
+    "cbas_debug_gemm_f8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
     "cbas_enc_profile": (c_int, [c_void_p, c_int]),
     "cbas_enc_profile_read": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double),
                                       c_int]),

@@ -33,6 +33,9 @@ struct LayerW {
     float* qkv_b;                       // [3D] = q.b | 0 | v.b
     f16 *wqkv, *wo, *wup, *wdown;       // fp16 (hi)
     f16 *wqkv_lo, *wo_lo, *wup_lo, *wdown_lo;
+    // precision 2: MX-fp8 copies (e4m3 bytes, same [N][K] layout) + E8M0 block scales [K/128][N] dwords
+    uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *wup8 = nullptr, *wdown8 = nullptr;
+    uint32_t *sqkv = nullptr, *so = nullptr, *sup = nullptr, *sdown = nullptr;
 };
 
 struct Slot {
@@ -59,6 +62,9 @@ struct cbas_enc {
     std::vector<LayerW> layers;
     const float *prefix, *patch_b, *norm_w, *norm_b;
     f16 *w16 = nullptr, *w16_lo = nullptr;     // all fp16 weights (hi / lo)
+    uint8_t* w8 = nullptr;                     // precision 2: all MX-fp8 weights
+    uint32_t* w8_sc = nullptr;                 //              and their block scales
+    uint32_t *sc_h = nullptr, *sc_u = nullptr; // precision 2: block scales of the fp8 activations in h16 / u16 ([K/128][rows_cap])
     f16 *wpatch, *wpatch2, *wpatch_lo, *wpatch2_lo;
     float* qkv_bias_all = nullptr;
     float* prefix_dev = nullptr;        // (1+R, D): cls (+ its position embedding for DINOv2) | registers
@@ -90,7 +96,7 @@ struct cbas_enc {
     // compute lanes, each a full workspace + its own stream, so that one batch's partial tile rounds,
     // LayerNorm and attention run under the other batch's GEMMs (+10 % measured; outputs bit-identical).
     // lane 0 = the buffers above on `compute`; the synchronous cbas_enc_forward_* always use lane 0.
-    struct Lane { f16 *A_patch, *h16, *qkv16, *u16, *cls16; float* x; hipStream_t stream; };
+    struct Lane { f16 *A_patch, *h16, *qkv16, *u16, *cls16; float* x; uint32_t *sc_h, *sc_u; hipStream_t stream; };
     Lane lanes[2] = {};
     int n_lanes = 1;
     uint64_t submit_count = 0;
@@ -286,20 +292,29 @@ int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t s
     f16* cc = qc + cap * D;                 // [n][D] attention context of the CLS rows
     f16* hc = cc + cap * D;                 // [n][D] LayerNorm 2 of the CLS rows
     f16* uc = hc + cap * D;                 // [n][F] GELU(up_proj)
-    const bool split = h->cfg.precision == 1;
-    { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+    const bool split = h->cfg.precision == 1, f8 = h->cfg.precision == 2;
+    const int sc_ld = (int)h->rows_cap;
     GemmParams kv{};                        // k | v sections of the fused QKV weight, all rows
-    kv.A = h->h16; kv.W = w.wqkv + (size_t)D * D; kv.W_lo = split ? w.wqkv_lo + (size_t)D * D : nullptr;
+    if (f8) {
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f8(h->x, D, w.ln1_w, w.ln1_b, (uint8_t*)h->h16, h->sc_h, sc_ld, M, D, h->cfg.layer_norm_eps, st)); }
+        // the CLS tail of this layer stays fp16 (fp16 weights, n rows): its LayerNorm 1 rows go to the LN2 slot for now
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, (int64_t)T * D, w.ln1_w, w.ln1_b, hc, n, D, h->cfg.layer_norm_eps, st)); }
+        kv.A8 = (const uint8_t*)h->h16; kv.A_sc = h->sc_h; kv.sc_lda = sc_ld;
+        kv.W8 = w.wqkv8 + (size_t)D * D; kv.W_sc = w.sqkv + D; kv.sc_ldw = 3 * D;
+    } else {
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+        kv.A = h->h16; kv.W = w.wqkv + (size_t)D * D; kv.W_lo = split ? w.wqkv_lo + (size_t)D * D : nullptr;
+    }
     kv.M = M; kv.M_pad = M_pad; kv.N = 2 * D; kv.K = D; kv.bias = w.qkv_b + D; kv.out_f16 = h->qkv16 + D; kv.ldo = 3 * D;
     kv.tokens_per_frame = T; kv.n_prefix = h->NP; kv.D = D; kv.sec0 = 1;
     kv.rope_cos = h->cfg.use_rope ? h->rope_cos : nullptr; kv.rope_sin = h->cfg.use_rope ? h->rope_sin : nullptr;
     { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, kv, st)); }
-    GemmParams q{};                         // q section, CLS rows only (row b*T of h16)
-    q.A = h->h16; q.lda = T * D; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr;
+    GemmParams q{};                         // q section, CLS rows only (row b*T of h16; the compact fp16 rows when f8)
+    q.A = f8 ? hc : h->h16; q.lda = f8 ? D : T * D; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr;
     q.M = n; q.M_pad = n; q.N = D; q.K = D; q.bias = w.qkv_b; q.out_f16 = qc; q.ldo = D;
     q.tokens_per_frame = 1; q.n_prefix = 1; q.D = D; q.sec0 = 0;      // every row is token 0: no RoPE
     { PROF(CBAS_PROF_QKV, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
-    { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * D); LAUNCH_TRY(launch_attention(h->qkv16, qc, cc, n, T, D, h->NH, st)); }
+    { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * D); LAUNCH_TRY(launch_attention(h->qkv16, qc, cc, nullptr, 0, n, T, D, h->NH, st)); }
     GemmParams o{};
     o.A = cc; o.W = w.wo; o.W_lo = split ? w.wo_lo : nullptr;
     o.M = n; o.M_pad = n; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out_f32 = h->x; o.ldo = T * D;
@@ -330,7 +345,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     GemmParams g{};
     g.A = h->A_patch;
     g.W = patch_k == 256 ? h->wpatch : h->wpatch2;
-    g.W_lo = h->cfg.precision ? (patch_k == 256 ? h->wpatch_lo : h->wpatch2_lo) : nullptr;
+    g.W_lo = h->cfg.precision == 1 ? (patch_k == 256 ? h->wpatch_lo : h->wpatch2_lo) : nullptr;
     g.M = n * P; g.M_pad = (int)round_up(n * P, 128); g.N = D; g.K = patch_k;
     g.bias = h->patch_b; g.out_f32 = h->x; g.ldo = D;
     g.patches_per_frame = P; g.tokens_per_frame = T; g.n_prefix = h->NP; g.in_scale = in_scale;
@@ -341,6 +356,11 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     // The last layer feeds only the final norm of the CLS rows, so everything after its K/V projection is
     // done for n rows instead of n*T (rows are independent: bit-identical CLS).  Debug taps run it in full.
     const bool prune = h->prune_last && stop_layer < 0 && (cls_f32 || cls_f16);
+    const bool split = h->cfg.precision == 1, f8 = h->cfg.precision == 2;
+    if (f8 && stop_layer >= 0) return cbas_fail(CBAS_EINVAL, "debug taps read fp16 buffers; not available with precision 2");
+    const int sc_ld = (int)h->rows_cap;
+    uint8_t* const h8 = reinterpret_cast<uint8_t*>(h->h16);      // fp8 activations live in the fp16 buffers' memory
+    uint8_t* const u8 = reinterpret_cast<uint8_t*>(h->u16);
     for (int l = 0; l < h->L; ++l) {
         const LayerW& w = h->layers[l];
         auto stop = [&](int stage) { return stop_layer == l && stop_stage == stage; };
@@ -349,37 +369,46 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
             if (rc) return rc;
             break;
         }
-        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+        if (f8) { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f8(h->x, D, w.ln1_w, w.ln1_b, h8, h->sc_h, sc_ld, M, D, h->cfg.layer_norm_eps, st)); }
+        else { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         if (stop(1)) return CBAS_OK;
 
         GemmParams q{};
-        q.A = h->h16; q.W = w.wqkv; q.W_lo = h->cfg.precision ? w.wqkv_lo : nullptr;
+        if (f8) { q.A8 = h8; q.A_sc = h->sc_h; q.sc_lda = sc_ld; q.W8 = w.wqkv8; q.W_sc = w.sqkv; }
+        else { q.A = h->h16; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr; }
         q.M = M; q.M_pad = M_pad; q.N = 3 * D; q.K = D; q.bias = w.qkv_b; q.out_f16 = h->qkv16; q.ldo = 3 * D;
         q.tokens_per_frame = T; q.n_prefix = h->NP; q.D = D;
         q.rope_cos = h->cfg.use_rope ? h->rope_cos : nullptr; q.rope_sin = h->cfg.use_rope ? h->rope_sin : nullptr;
         { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
         if (stop(2)) return CBAS_OK;
 
-        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention(h->qkv16, nullptr, h->h16, n, T, D, h->NH, st)); }
+        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D);
+          LAUNCH_TRY(launch_attention(h->qkv16, nullptr, h->h16, f8 ? h->sc_h : nullptr, sc_ld, n, T, D, h->NH, st)); }
         if (stop(3)) return CBAS_OK;
 
         GemmParams o{};
-        o.A = h->h16; o.W = w.wo; o.W_lo = h->cfg.precision ? w.wo_lo : nullptr;
+        if (f8) { o.A8 = h8; o.A_sc = h->sc_h; o.sc_lda = sc_ld; o.W8 = w.wo8; o.W_sc = w.so; }
+        else { o.A = h->h16; o.W = w.wo; o.W_lo = split ? w.wo_lo : nullptr; }
         o.M = M; o.M_pad = M_pad; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out_f32 = h->x; o.ldo = D;
         { PROF(CBAS_PROF_OPROJ, 2.0 * M * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_RESID, o, st)); }
         if (stop(4)) return CBAS_OK;
 
-        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
+        if (f8) { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f8(h->x, D, w.ln2_w, w.ln2_b, h8, h->sc_h, sc_ld, M, D, h->cfg.layer_norm_eps, st)); }
+        else { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln2_w, w.ln2_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         if (stop(5)) return CBAS_OK;
 
         GemmParams u{};
-        u.A = h->h16; u.W = w.wup; u.W_lo = h->cfg.precision ? w.wup_lo : nullptr;
-        u.M = M; u.M_pad = M_pad; u.N = F; u.K = D; u.bias = w.up_b; u.out_f16 = h->u16; u.ldo = F;
-        { PROF(CBAS_PROF_UP, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_GELU, u, st)); }
+        if (f8) {
+            u.A8 = h8; u.A_sc = h->sc_h; u.sc_lda = sc_ld; u.W8 = w.wup8; u.W_sc = w.sup;
+            u.out_f8 = u8; u.out_sc = h->sc_u; u.sc_ldo = sc_ld;
+        } else { u.A = h->h16; u.W = w.wup; u.W_lo = split ? w.wup_lo : nullptr; u.out_f16 = h->u16; }
+        u.M = M; u.M_pad = M_pad; u.N = F; u.K = D; u.bias = w.up_b; u.ldo = F;
+        { PROF(CBAS_PROF_UP, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(f8 ? EPI_GELU_F8 : EPI_GELU, u, st)); }
         if (stop(6)) return CBAS_OK;
 
         GemmParams d{};
-        d.A = h->u16; d.W = w.wdown; d.W_lo = h->cfg.precision ? w.wdown_lo : nullptr;
+        if (f8) { d.A8 = u8; d.A_sc = h->sc_u; d.sc_lda = sc_ld; d.W8 = w.wdown8; d.W_sc = w.sdown; }
+        else { d.A = h->u16; d.W = w.wdown; d.W_lo = split ? w.wdown_lo : nullptr; }
         d.M = M; d.M_pad = M_pad; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out_f32 = h->x; d.ldo = D;
         { PROF(CBAS_PROF_DOWN, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_RESID, d, st)); }
         if (stop(7)) return CBAS_OK;
@@ -405,6 +434,7 @@ int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, in
 void use_lane(cbas_enc* h, int l) {
     const cbas_enc::Lane& L = h->lanes[l];
     h->A_patch = L.A_patch; h->x = L.x; h->h16 = L.h16; h->qkv16 = L.qkv16; h->u16 = L.u16; h->cls16 = L.cls16;
+    h->sc_h = L.sc_h; h->sc_u = L.sc_u;
 }
 
 int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
@@ -444,12 +474,13 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
     if (h->lane0_async_done) (void)hipEventDestroy(h->lane0_async_done);
     if (h->sync_done) (void)hipEventDestroy(h->sync_done);
     {
-        void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16, h->lanes[1].cls16};
+        void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16, h->lanes[1].cls16,
+                      h->lanes[1].sc_h, h->lanes[1].sc_u};
         for (void* b : b1) if (b) (void)hipFree(b);
     }
     for (auto& t : h->pos_tables) { if (t.cos) (void)hipFree(t.cos); if (t.sin) (void)hipFree(t.sin); if (t.pos) (void)hipFree(t.pos); }
     void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->prefix_dev,
-                    h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16};
+                    h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16, h->w8, h->w8_sc, h->sc_h, h->sc_u};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->compute) (void)hipStreamDestroy(h->compute);
@@ -469,6 +500,10 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         return cbas_fail(CBAS_EINVAL, "intermediate_size=%d must be a multiple of 128", c.intermediate_size);
     if (c.hidden_size > 1024) return cbas_fail(CBAS_EINVAL, "hidden_size > 1024 not supported");
     if (c.patch_size != 16 && c.patch_size != 14) return cbas_fail(CBAS_EINVAL, "patch_size must be 14 or 16");
+    if (c.precision < 0 || c.precision > 2) return cbas_fail(CBAS_EINVAL, "precision=%d: 0 (fp16), 1 (fp16 hi+lo weights) or 2 (MX-fp8)", c.precision);
+    if (c.precision == 2 && (c.hidden_size % 256 || c.intermediate_size % 256))
+        return cbas_fail(CBAS_EINVAL, "precision 2 (MX-fp8) needs hidden_size and intermediate_size to be multiples of 256 "
+                                      "(K-tiles of 128 consumed in pairs); got %d / %d", c.hidden_size, c.intermediate_size);
     if ((c.use_rope != 0) == (c.pos_embed_grid > 0))
         return cbas_fail(CBAS_EINVAL, "exactly one of use_rope / pos_embed_grid must be set");
     if (c.num_layers <= 0 || c.num_register_tokens < 0 || c.max_batch <= 0 || c.max_height < c.patch_size || c.max_width < c.patch_size)
@@ -503,7 +538,15 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     // fp16 weight arena: patch (D*256 + D*512) + per layer (3DD + DD + FD + DF)
     const int64_t n16 = D * 256 + D * 512 + (int64_t)h->L * (4 * D * D + 2 * F * D);
     CREATE_TRY(hipMalloc(&h->w16, n16 * sizeof(f16)));
-    if (c.precision) CREATE_TRY(hipMalloc(&h->w16_lo, n16 * sizeof(f16)));
+    if (c.precision == 1) CREATE_TRY(hipMalloc(&h->w16_lo, n16 * sizeof(f16)));
+    uint8_t* w8p = nullptr;
+    uint32_t* s8p = nullptr;
+    if (c.precision == 2) {
+        const int64_t n8 = (int64_t)h->L * (4 * D * D + 2 * F * D);
+        CREATE_TRY(hipMalloc(&h->w8, n8));
+        CREATE_TRY(hipMalloc(&h->w8_sc, n8 / 32));              // one E8M0 byte per 32 elements
+        w8p = h->w8; s8p = h->w8_sc;
+    }
     CREATE_TRY(hipMalloc(&h->qkv_bias_all, (int64_t)h->L * 3 * D * sizeof(float)));
     CREATE_TRY(hipMemset(h->qkv_bias_all, 0, (int64_t)h->L * 3 * D * sizeof(float)));
 
@@ -567,6 +610,18 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         rc |= launch_convert_f16(ow, lw.wo, lw.wo_lo, D * D, st);
         rc |= launch_convert_f16(uw, lw.wup, lw.wup_lo, F * D, st);
         rc |= launch_convert_f16(dw, lw.wdown, lw.wdown_lo, D * F, st);
+        if (c.precision == 2) {
+            lw.wqkv8 = w8p; w8p += 3 * D * D;  lw.sqkv = s8p; s8p += 3 * D * D / 128;
+            lw.wo8 = w8p; w8p += D * D;        lw.so = s8p; s8p += D * D / 128;
+            lw.wup8 = w8p; w8p += F * D;       lw.sup = s8p; s8p += F * D / 128;
+            lw.wdown8 = w8p; w8p += D * F;     lw.sdown = s8p; s8p += D * F / 128;
+            rc |= launch_pack_fp8_weight(qw, lw.wqkv8, lw.sqkv, (int)D, (int)D, (int)(3 * D), 0, st);
+            rc |= launch_pack_fp8_weight(kw, lw.wqkv8 + D * D, lw.sqkv, (int)D, (int)D, (int)(3 * D), (int)D, st);
+            rc |= launch_pack_fp8_weight(vw, lw.wqkv8 + 2 * D * D, lw.sqkv, (int)D, (int)D, (int)(3 * D), (int)(2 * D), st);
+            rc |= launch_pack_fp8_weight(ow, lw.wo8, lw.so, (int)D, (int)D, (int)D, 0, st);
+            rc |= launch_pack_fp8_weight(uw, lw.wup8, lw.sup, (int)F, (int)D, (int)F, 0, st);
+            rc |= launch_pack_fp8_weight(dw, lw.wdown8, lw.sdown, (int)D, (int)F, (int)D, 0, st);
+        }
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b, qb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b + D, kb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b + 2 * D, vb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -592,6 +647,13 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     CREATE_TRY(hipMalloc(&h->h16, h->rows_cap * D * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->qkv16, h->rows_cap * 3 * D * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->u16, h->rows_cap * F * sizeof(f16)));
+    const int64_t sch_elems = (D / 128) * h->rows_cap, scu_elems = (F / 128) * h->rows_cap;    // dwords
+    if (c.precision == 2) {
+        CREATE_TRY(hipMalloc(&h->sc_h, sch_elems * 4));
+        CREATE_TRY(hipMalloc(&h->sc_u, scu_elems * 4));
+        CREATE_TRY(hipMemsetAsync(h->sc_h, 0, sch_elems * 4, st));
+        CREATE_TRY(hipMemsetAsync(h->sc_u, 0, scu_elems * 4, st));
+    }
     const int64_t cls_elems = round_up(c.max_batch, 128) * (3 * D + F);
     CREATE_TRY(hipMalloc(&h->cls16, cls_elems * sizeof(f16)));
     CREATE_TRY(hipMemsetAsync(h->cls16, 0, cls_elems * sizeof(f16), st));
@@ -605,7 +667,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         const char* e = getenv("CBAS_LANES");
         h->n_lanes = (e && atoi(e) == 1) ? 1 : 2;
         cbas_enc::Lane& L0 = h->lanes[0];
-        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16; L0.cls16 = h->cls16; L0.stream = h->compute;
+        L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16; L0.cls16 = h->cls16; L0.sc_h = h->sc_h; L0.sc_u = h->sc_u; L0.stream = h->compute;
         if (h->n_lanes == 2) {
             cbas_enc::Lane& L1 = h->lanes[1];
             CREATE_TRY(hipMalloc(&L1.A_patch, h->prow_cap * 512 * sizeof(f16)));
@@ -613,6 +675,12 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
             CREATE_TRY(hipMalloc(&L1.h16, h->rows_cap * D * sizeof(f16)));
             CREATE_TRY(hipMalloc(&L1.qkv16, h->rows_cap * 3 * D * sizeof(f16)));
             CREATE_TRY(hipMalloc(&L1.u16, h->rows_cap * F * sizeof(f16)));
+            if (c.precision == 2) {
+                CREATE_TRY(hipMalloc(&L1.sc_h, sch_elems * 4));
+                CREATE_TRY(hipMalloc(&L1.sc_u, scu_elems * 4));
+                CREATE_TRY(hipMemsetAsync(L1.sc_h, 0, sch_elems * 4, st));
+                CREATE_TRY(hipMemsetAsync(L1.sc_u, 0, scu_elems * 4, st));
+            }
             CREATE_TRY(hipMalloc(&L1.cls16, cls_elems * sizeof(f16)));
             CREATE_TRY(hipMemsetAsync(L1.cls16, 0, cls_elems * sizeof(f16), st));
             CREATE_TRY(hipMemsetAsync(L1.A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
@@ -1021,5 +1089,49 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, cs, 8, hipMemcpyDeviceToHost));
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32);
+    return CBAS_OK;
+}
+
+// Bring-up / test harness of the MX-fp8 GEMM: quantise A [M][K] and W [N][K] (fp32, host) with the library's own
+// block quantiser, run out = A_q * W_q^T through the fp8 ping-pong kernel (residual epilogue on a zero stream with
+// bias 0 and lambda 1), and hand back the product together with the quantised operands, so a test can recompute it
+// from exactly those bytes and scales.  A_sc / W_sc: [K/128][M_pad resp. N] dwords (GemmParams layout), M_pad = M up to 256.
+extern "C" int cbas_debug_gemm_f8(int M, int N, int K, int tile, const float* A_host, const float* W_host, float* out_host,
+                                  uint8_t* A8_host, uint32_t* Asc_host, uint8_t* W8_host, uint32_t* Wsc_host) {
+    if (M <= 0 || N % 256 || K % 256 || !A_host || !W_host || !out_host) return cbas_fail(CBAS_EINVAL, "bad fp8 GEMM test shape");
+    const int64_t M_pad = round_up(M, 256);
+    float *A = nullptr, *W = nullptr, *x = nullptr, *bias = nullptr, *lam = nullptr;
+    uint8_t *A8 = nullptr, *W8 = nullptr;
+    uint32_t *Asc = nullptr, *Wsc = nullptr;
+    HIP_TRY(hipMalloc(&A, M_pad * (int64_t)K * 4));
+    HIP_TRY(hipMalloc(&W, (int64_t)N * K * 4));
+    HIP_TRY(hipMalloc(&x, M_pad * (int64_t)N * 4));
+    HIP_TRY(hipMalloc(&bias, (int64_t)N * 4));
+    HIP_TRY(hipMalloc(&lam, (int64_t)N * 4));
+    HIP_TRY(hipMalloc(&A8, M_pad * (int64_t)K));
+    HIP_TRY(hipMalloc(&W8, (int64_t)N * K));
+    HIP_TRY(hipMalloc(&Asc, M_pad * (int64_t)K / 32));
+    HIP_TRY(hipMalloc(&Wsc, (int64_t)N * K / 32));
+    HIP_TRY(hipMemset(A, 0, M_pad * (int64_t)K * 4));
+    HIP_TRY(hipMemset(x, 0, M_pad * (int64_t)N * 4));
+    HIP_TRY(hipMemset(bias, 0, (int64_t)N * 4));
+    HIP_TRY(hipMemcpy(A, A_host, (int64_t)M * K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(W, W_host, (int64_t)N * K * 4, hipMemcpyHostToDevice));
+    std::vector<float> ones((size_t)N, 1.0f);
+    HIP_TRY(hipMemcpy(lam, ones.data(), (int64_t)N * 4, hipMemcpyHostToDevice));
+    LAUNCH_TRY(launch_pack_fp8_weight(A, A8, Asc, (int)M_pad, K, (int)M_pad, 0, 0));
+    LAUNCH_TRY(launch_pack_fp8_weight(W, W8, Wsc, N, K, N, 0, 0));
+    GemmParams p{};
+    p.tile = tile; p.A8 = A8; p.W8 = W8; p.A_sc = Asc; p.W_sc = Wsc; p.sc_lda = (int)M_pad;
+    p.M = M; p.M_pad = (int)M_pad; p.N = N; p.K = K; p.lda = K; p.bias = bias; p.lambda = lam; p.out_f32 = x; p.ldo = N;
+    int rc = tile ? launch_gemm_8ph(EPI_RESID, p, tile, 0) : launch_gemm(EPI_RESID, p, 0);
+    if (rc) return cbas_fail(CBAS_EINVAL, "fp8 GEMM launch failed (rc=%d)", rc);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_host, x, (int64_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (A8_host) HIP_TRY(hipMemcpy(A8_host, A8, (int64_t)M * K, hipMemcpyDeviceToHost));
+    if (Asc_host) HIP_TRY(hipMemcpy(Asc_host, Asc, M_pad * (int64_t)K / 32, hipMemcpyDeviceToHost));
+    if (W8_host) HIP_TRY(hipMemcpy(W8_host, W8, (int64_t)N * K, hipMemcpyDeviceToHost));
+    if (Wsc_host) HIP_TRY(hipMemcpy(Wsc_host, Wsc, (int64_t)N * K / 32, hipMemcpyDeviceToHost));
+    hipFree(A); hipFree(W); hipFree(x); hipFree(bias); hipFree(lam); hipFree(A8); hipFree(W8); hipFree(Asc); hipFree(Wsc);
     return CBAS_OK;
 }

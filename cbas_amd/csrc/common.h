@@ -49,6 +49,7 @@ static __device__ __forceinline__ float gelu_fast(float x) {
 
 // ---- MX-fp8 (OCP e4m3 elements, E8M0 scale per 32-element block) -------------------------------------------------
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 // E8M0 byte of the smallest power-of-two scale s with amax / s <= 448 (the largest e4m3 value): no element clips.
 // amax = 1.f * 2^(E-127); 448 = 1.75 * 2^8  =>  byte = E - 8 (+1 when the fraction exceeds .75), clamped to [0, 253].
 static __device__ __forceinline__ int mx_scale_byte(float amax) {

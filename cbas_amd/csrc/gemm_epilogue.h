@@ -188,7 +188,31 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const int r = it * 8 + (lane >> 3), c = lane & 7;      // 8 rows x 128 bytes per wave store
                 const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = row_base + half * 64 + r;
-                if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
+                if (EPI == EPI_GELU_F8) {
+                    // MX-fp8 store: the lane holds 8 consecutive columns of row m; a 32-column scale block is the 4 lanes
+                    // c = 0..3 (or 4..7).  The wave's 64 columns are blocks (head_col0 % 128) / 32 + {0, 1} of K-tile
+                    // head_col0 / 128 of the consumer (the down projection).
+                    float f[8], a = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { f[e] = (float)hv[e]; a = fmaxf(a, fabsf(f[e])); }
+                    a = fmaxf(a, __shfl_xor(a, 1, 64));
+                    a = fmaxf(a, __shfl_xor(a, 2, 64));
+                    const int sb = mx_scale_byte(a);
+                    const float inv = mx_inv_scale(sb);
+                    const int sb_hi = __shfl_xor(sb, 4, 64);
+                    uint2 q;
+                    q.x = cvt4_e4m3(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
+                    q.y = cvt4_e4m3(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
+                    if (m < p.M) {
+                        *reinterpret_cast<uint2*>(p.out_f8 + (size_t)m * p.ldo + head_col0 + c * 8) = q;
+                        if (c == 0)
+                            *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(p.out_sc) +
+                                                         ((size_t)(head_col0 >> 7) * p.sc_ldo + m) * 4 + ((head_col0 & 127) >> 5)) =
+                                (uint16_t)(sb | (sb_hi << 8));
+                    }
+                } else {
+                    if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
+                }
             }
             asm volatile("" ::: "memory");
         }

@@ -230,6 +230,12 @@ int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
     if (!p.lda) p.lda = p.K;
     if (p.N % 128 || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
     if (epi == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;
+    if (p.A8) {           // MX-fp8 operands exist only in the ping-pong kernel; small problems take its 128-row tile
+        if (p.N % 256) return -1;
+        const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+        return launch_gemm_8ph(epi, p, t256 >= 120 ? GEMM_TILE_PP_AUTO : GEMM_TILE_PP_128x256, stream);
+    }
+    if (epi == EPI_GELU_F8) return -1;
     const int tile = pick_tile(p);
     int rc = dispatch_gemm(epi, p, tile, stream);
     if (rc == -1 && tile != GEMM_TILE_128x128) rc = dispatch_gemm(epi, p, GEMM_TILE_128x128, stream);   // shape not tileable that way

@@ -29,6 +29,15 @@
 // hands out workgroups in block order, so the small tiles fill the last, partial round of the big
 // ones (612 big tiles on 256 CUs are 3 rounds; 504 big + 204 half-size tiles finish in about 2.65).
 //
+// MX-fp8 form (F8 = true, precision 2): operands are e4m3 bytes with one E8M0 scale per 32 k-elements.  A K-tile is
+// 128 k-elements = the same 128-byte LDS rows, swizzle, staging schedule and fragment reads as the fp16 form; the two
+// 16-byte fragment reads of a lane (chunks q and 4+q of a row, q = lane >> 4) are exactly the 32 bytes
+// v_mfma_scale_f32_16x16x128_f8f6f4 wants from it (k = 16q..16q+15 and 64+16q..64+16q+15; probed on gfx950 with
+// scripts/probes/probe_mfma_scale.hip), and the scale of block b of a row comes from lane q = b.  So the K loop issues
+// ONE scaled MFMA where the fp16 form issues two, at twice the k per staged byte.  The block scales of a K-tile (4 bytes
+// per row, 2 KiB per tile pair) ride along as one extra 4-byte LDS-DMA per wave issued with the A-sub1 sub-tile, and are
+// read with the fragments they belong to.
+//
 // Reference arithmetic replaced: the same nn.Linear calls as gemm_f16.hip ([tf] modeling_dinov3_vit.py
 // :307-309, :331, :356-357).
 #include <stdlib.h>
@@ -53,7 +62,7 @@ __device__ __forceinline__ f16x8 read_frag8(const char* lds_tile, int off) {
     return *reinterpret_cast<const f16x8*>(lds_tile + off);
 }
 
-template <int EPI, int TA, int TB>
+template <int EPI, int TA, int TB, bool F8>
 __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0, char* smem) {
     constexpr int TM = TA + TB;                      // 16-row MFMA tiles per wave
     constexpr int WROWS = 16 * TM;                   // rows of C per wave
@@ -64,7 +73,11 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int nk = p.K / BK;                          // even, >= 2 (checked by the launcher)
+    const int nk = p.K / (F8 ? 2 * BK : BK);           // even, >= 2 (checked by the launcher)
+    constexpr int ESZ = F8 ? 1 : 2;                    // bytes per operand element: a K-tile is always 128 bytes per row
+    const char* Abase = F8 ? reinterpret_cast<const char*>(p.A8) : reinterpret_cast<const char*>(p.A);
+    const char* Wbase = F8 ? reinterpret_cast<const char*>(p.W8) : reinterpret_cast<const char*>(p.W);
+    char* const sc_lds = smem + 2 * BUF_BYTES;         // F8: [buf][A rows 256 x 4 B | B rows 256 x 4 B]
 
     // ---- LDS-DMA source offsets: two 8-row pieces per wave and sub-tile --------------------------
     // A-sub0 = rows {wr' * WROWS + [0, 16 TA)}, A-sub1 = rows {wr' * WROWS + 16 TA + [0, 16 TB)}, wr' = 0,1;
@@ -86,13 +99,27 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
             const int r = ar + lrow;
             int grow = row0 + r;
             grow = grow < p.M_pad - 1 ? grow : p.M_pad - 1;
-            a_src[h][s] = (unsigned)grow * (unsigned)p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+            a_src[h][s] = (unsigned)grow * (unsigned)(p.lda * ESZ) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);     // bytes
             const int qb = wave + 8 * s;
             const int br = (((qb >> 2) << 3) | (h << 2) | (qb & 3)) * 8;
             b_lds[h][s] = A_BYTES + br * 128;
             const int rb = br + lrow;
-            b_src[h][s] = (unsigned)(col0 + rb) * (unsigned)p.K + (((lane & 7) ^ ((rb >> 1) & 7)) << 3);
+            b_src[h][s] = (unsigned)(col0 + rb) * (unsigned)(p.K * ESZ) + (((lane & 7) ^ ((rb >> 1) & 7)) << 4);
         }
+    // F8: block scales of one K-tile.  Waves 0-3 fetch the dwords of A rows row0 + 64*wave + lane, waves 4-7 those of
+    // W rows col0 + 64*(wave-4) + lane (rows past the tile / past M_pad are clamped or belong to a neighbour: never used)
+    const uint32_t* sc_src = nullptr;
+    int sc_step = 0, sc_dst = 0;
+    if (F8) {
+        if (wave < 4) {
+            int r = row0 + wave * 64 + lane;
+            r = r < p.M_pad - 1 ? r : p.M_pad - 1;
+            sc_src = p.A_sc + r; sc_step = p.sc_lda;
+        } else {
+            sc_src = p.W_sc + col0 + (wave - 4) * 64 + lane; sc_step = p.sc_ldw ? p.sc_ldw : p.N;
+        }
+        sc_dst = wave * 256;
+    }
     // which: 0 = B-sub0, 1 = A-sub0, 2 = B-sub1, 3 = A-sub1 (the issue order within a K-tile)
     auto stage = [&](int buf, int kt, int which) {
         char* base = smem + buf * BUF_BYTES;
@@ -100,11 +127,13 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
         if (which & 1) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + a_src[h][s] + kt * BK), LDS_PTR(base + a_lds[h][s]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(Abase + a_src[h][s] + kt * 128), LDS_PTR(base + a_lds[h][s]), 16, 0, 0);
+            if (F8 && h == 1)        // rides with A-sub1: retired by the same counted vmcnt, two barriers before its first read
+                __builtin_amdgcn_global_load_lds(GLB_PTR(sc_src + (size_t)kt * sc_step), LDS_PTR(sc_lds + buf * 2048 + sc_dst), 4, 0, 0);
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(p.W + b_src[h][s] + kt * BK), LDS_PTR(base + b_lds[h][s]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(Wbase + b_src[h][s] + kt * 128), LDS_PTR(base + b_lds[h][s]), 16, 0, 0);
         }
     };
 
@@ -117,6 +146,10 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
         a_off[kk] = (wr * WROWS + frow) * 128 + sw;
         b_off[kk] = A_BYTES + (wc * 64 + frow) * 128 + sw;
     }
+
+    // F8: byte of lane (frow, q = fchunk) in the scale image: row * 4 + q
+    const int sa_off = (wr * WROWS + frow) * 4 + fchunk;              // + (I0 + i) * 64
+    const int sb_off = 1024 + (wc * 64 + frow) * 4 + fchunk;          // + (h * 2 + j) * 64
 
     f32x4 acc[TM][4];
 #pragma unroll
@@ -135,7 +168,10 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
     if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
 
-    f16x8 a[TMAX][2], b0[2][2], b1[2][2];
+    // fragments: fp16 form = two 16-byte k-halves per 16-row tile; F8 form = the same two reads joined into the
+    // 8-register operand of the scaled MFMA (a register sequence, no copies) + its E8M0 scale byte
+    struct Frag { f16x8 h[2]; i32x8 v; int sc; };
+    Frag a[TMAX], b0[2], b1[2];
 
 #define CBAS_SEG_BARRIER()                      \
     do {                                        \
@@ -144,61 +180,86 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
 
-    auto mfma_quadrant = [&](auto ha_c, f16x8 (&bf)[2][2], int hb) {
+    auto mfma_quadrant = [&](auto ha_c, Frag (&bf)[2], int hb) {
         constexpr int ha = decltype(ha_c)::value;
         constexpr int T = ha ? TB : TA, I0 = ha ? TA : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[I0 + i][hb * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][kk], a[i][kk], acc[I0 + i][hb * 2 + j], 0, 0, 0);
+                    acc[I0 + i][hb * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        bf[j].v, a[i].v, acc[I0 + i][hb * 2 + j], 0, 0, 0, bf[j].sc, 0, a[i].sc);
+            // hipcc (ROCm 7.2) sinks the scaled MFMAs out of their phase to the end of the loop body (their results are
+            // only consumed there); an empty volatile asm that "uses" each accumulator pins them inside the setprio window
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[I0 + i][hb * 2 + j]));
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[I0 + i][hb * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j].h[kk], a[i].h[kk], acc[I0 + i][hb * 2 + j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
-    auto read_a = [&](const char* buf, auto h_c) {
+    auto read_frag = [&](Frag& f, const char* buf, int off0, int off1, const char* scb, int sc_off) {
+        if constexpr (F8) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(buf + off0), hi = *reinterpret_cast<const i32x4*>(buf + off1);
+            f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            f.sc = *reinterpret_cast<const unsigned char*>(scb + sc_off);
+        } else {
+            f.h[0] = read_frag8(buf, off0);
+            f.h[1] = read_frag8(buf, off1);
+        }
+    };
+    auto read_a = [&](const char* buf, const char* scb, auto h_c) {
         constexpr int h = decltype(h_c)::value;
         constexpr int T = h ? TB : TA, I0 = h ? TA : 0;
 #pragma unroll
         for (int i = 0; i < T; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) a[i][kk] = read_frag8(buf, a_off[kk] + (I0 + i) * 2048);
+            read_frag(a[i], buf, a_off[0] + (I0 + i) * 2048, a_off[1] + (I0 + i) * 2048, scb, sa_off + (I0 + i) * 64);
     };
-    auto read_b = [&](const char* buf, int h, f16x8 (&bf)[2][2]) {
+    auto read_b = [&](const char* buf, const char* scb, int h, Frag (&bf)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) bf[j][kk] = read_frag8(buf, b_off[kk] + (h * 2 + j) * 2048);
+            read_frag(bf[j], buf, b_off[0] + (h * 2 + j) * 2048, b_off[1] + (h * 2 + j) * 2048, scb, sb_off + (h * 2 + j) * 64);
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
 
     auto ktile = [&](int b, int t) {
         const char* buf = smem + b * BUF_BYTES;
+        const char* scb = sc_lds + b * 2048;
         // P1
-        read_b(buf, 0, b0);
+        read_b(buf, scb, 0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(buf, H0{});
+        read_a(buf, scb, H0{});
         if (t + 1 < nk) stage(b ^ 1, t + 1, 3);
-        // the 4 B-sub0 reads (issued first) are retired: 2*TA A reads may still be in flight
-        if (TA == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        else if (TA == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        // the B-sub0 reads (issued first: 4 fragments, + 2 scale bytes when F8) are retired: the A reads issued after
+        // them (2*TA fragments, + TA scale bytes when F8) may still be in flight
+        if (TA == 4) { if (F8) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
+        else if (TA == 3) { if (F8) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }
+        else { if (F8) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
         CBAS_SEG_BARRIER();
         mfma_quadrant(H0{}, b0, 0);
         CBAS_SEG_BARRIER();
         // P2
-        read_b(buf, 1, b1);
+        read_b(buf, scb, 1, b1);
         if (t + 2 < nk) stage(b, t + 2, 0);
         CBAS_SEG_BARRIER();
         mfma_quadrant(H0{}, b1, 1);
         CBAS_SEG_BARRIER();
         // P3
-        read_a(buf, H1{});
+        read_a(buf, scb, H1{});
         if (t + 2 < nk) stage(b, t + 2, 1);
         CBAS_SEG_BARRIER();
         mfma_quadrant(H1{}, b1, 1);
@@ -232,30 +293,30 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
 }
 
 // TAIL = 1: blocks past g.main_blocks run 128x256 tiles over rows [g.tail_row0, M)
-template <int EPI, int TA, int TB, int TAIL>
+template <int EPI, int TA, int TB, int TAIL, bool F8>
 __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGrid g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N / BN;
     if (!TAIL || (int)blockIdx.x < g.main_blocks) {
         const int bid = gemm_xcd_remap(blockIdx.x, TAIL ? g.main_blocks : (int)gridDim.x);
         const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-        pp_tile<EPI, TA, TB>(p, tm * 32 * (TA + TB), tn * BN, smem);
+        pp_tile<EPI, TA, TB, F8>(p, tm * 32 * (TA + TB), tn * BN, smem);
     } else {
         const int bid = gemm_xcd_remap(blockIdx.x - g.main_blocks, gridDim.x - g.main_blocks);
         const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-        pp_tile<EPI, 2, 2>(p, g.tail_row0 + tm * 128, tn * BN, smem);
+        pp_tile<EPI, 2, 2, F8>(p, g.tail_row0 + tm * 128, tn * BN, smem);
     }
 }
 
-template <int EPI, int TA, int TB, int TAIL>
+template <int EPI, int TA, int TB, int TAIL, bool F8>
 int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     constexpr int BM = 32 * (TA + TB);
-    constexpr int lds = 2 * (BM * 128 + BN * 128);
+    constexpr int lds = 2 * (BM * 128 + BN * 128) + (F8 ? 4096 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static_assert(lds >= 8 * 8192 && 2 * (128 * 128 + BN * 128) >= 8 * 8192, "epilogue scratch");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_8ph_kernel<EPI, TA, TB, TAIL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
@@ -273,7 +334,7 @@ int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
         g.main_blocks = grid;
         g.tail_row0 = p.M;
     }
-    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL>), dim3(grid), dim3(512), lds, stream, p, g);
+    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>), dim3(grid), dim3(512), lds, stream, p, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -331,33 +392,42 @@ PPPlan pp_plan(int M, int N) {
     return best;
 }
 
-template <int EPI>
+template <int EPI, bool F8>
 int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
-    if (tile == GEMM_TILE_PP_192x256) return launch_8ph<EPI, 3, 3, 0>(p, 0, stream);
-    if (tile == GEMM_TILE_PP_160x256) return launch_8ph<EPI, 3, 2, 0>(p, 0, stream);
-    if (tile == GEMM_TILE_PP_128x256) return launch_8ph<EPI, 2, 2, 0>(p, 0, stream);
-    if (tile == GEMM_TILE_PP_256x256) return launch_8ph<EPI, 4, 4, 0>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_192x256) return launch_8ph<EPI, 3, 3, 0, F8>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_160x256) return launch_8ph<EPI, 3, 2, 0, F8>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_128x256) return launch_8ph<EPI, 2, 2, 0, F8>(p, 0, stream);
+    if (tile == GEMM_TILE_PP_256x256) return launch_8ph<EPI, 4, 4, 0, F8>(p, 0, stream);
     // GEMM_TILE_PP_AUTO: uniform 256 / 192 / 160-row tiles, or 256-row tiles with a 128-row tail
     PPPlan plan = pp_plan(p.M, p.N);
     static const int mp_env = [] { const char* e = getenv("CBAS_PP_MAIN_PANELS"); return e ? atoi(e) : -1; }();
     if (mp_env >= 0 && mp_env * 256 < p.M) plan = {256, mp_env};                 // experiments only
-    if (plan.main_panels) return launch_8ph<EPI, 4, 4, 1>(p, plan.main_panels, stream);
-    if (plan.bm == 192) return launch_8ph<EPI, 3, 3, 0>(p, 0, stream);
-    if (plan.bm == 160) return launch_8ph<EPI, 3, 2, 0>(p, 0, stream);
-    return launch_8ph<EPI, 4, 4, 0>(p, 0, stream);
+    if (plan.main_panels) return launch_8ph<EPI, 4, 4, 1, F8>(p, plan.main_panels, stream);
+    if (plan.bm == 192) return launch_8ph<EPI, 3, 3, 0, F8>(p, 0, stream);
+    if (plan.bm == 160) return launch_8ph<EPI, 3, 2, 0, F8>(p, 0, stream);
+    return launch_8ph<EPI, 4, 4, 0, F8>(p, 0, stream);
 }
 
 }  // namespace
 
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
-    // 32-bit element offsets into A / W; K-tiles are consumed in pairs
-    if (p.W_lo || p.N % 256 || p.K % (2 * BK) || (long long)p.M_pad * p.lda >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31))
-        return -1;
-    switch (epi) {
-        case EPI_PATCH: return launch_8ph_epi<EPI_PATCH>(p, tile, stream);
-        case EPI_QKV:   return launch_8ph_epi<EPI_QKV>(p, tile, stream);
-        case EPI_RESID: return launch_8ph_epi<EPI_RESID>(p, tile, stream);
-        case EPI_GELU:  return launch_8ph_epi<EPI_GELU>(p, tile, stream);
+    // 32-bit byte offsets into A / W; K-tiles are consumed in pairs
+    if (p.W_lo || p.N % 256 || (long long)p.M_pad * p.lda >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31)) return -1;
+    if (p.A8) {                                        // MX-fp8 operands: 128-element K-tiles
+        if (p.K % (4 * BK) || !p.W8 || !p.A_sc || !p.W_sc) return -1;
+        switch (epi) {
+            case EPI_QKV:     return launch_8ph_epi<EPI_QKV, true>(p, tile, stream);
+            case EPI_RESID:   return launch_8ph_epi<EPI_RESID, true>(p, tile, stream);
+            case EPI_GELU_F8: return launch_8ph_epi<EPI_GELU_F8, true>(p, tile, stream);
+            default: return -1;
+        }
     }
-    return -1;
+    if (p.K % (2 * BK)) return -1;
+    switch (epi) {
+        case EPI_PATCH: return launch_8ph_epi<EPI_PATCH, false>(p, tile, stream);
+        case EPI_QKV:   return launch_8ph_epi<EPI_QKV, false>(p, tile, stream);
+        case EPI_RESID: return launch_8ph_epi<EPI_RESID, false>(p, tile, stream);
+        case EPI_GELU:  return launch_8ph_epi<EPI_GELU, false>(p, tile, stream);
+        default: return -1;
+    }
 }

@@ -35,8 +35,9 @@ struct GemmParams {
     const uint8_t* A8;   // [M_pad][lda]
     const uint8_t* W8;   // [N][K]
     const uint32_t* A_sc;   // [K/128][sc_lda]
-    const uint32_t* W_sc;   // [K/128][N]
+    const uint32_t* W_sc;   // [K/128][sc_ldw]
     int sc_lda;
+    int sc_ldw;          // 0: N (W_sc may point into a wider array, e.g. the k|v columns of the fused q|k|v scales)
     uint8_t* out_f8;     // EPI_GELU_F8: [M][ldo] bytes
     uint32_t* out_sc;    // EPI_GELU_F8: [N/128][sc_ldo]
     int sc_ldo;
@@ -100,7 +101,8 @@ int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_
 // patch weight (D,3,16,16) fp32 -> sum over the 3 identical input channels -> (D,256) fp16 hi (+lo),
 // and the same duplicated along K as (D,512) for the float-input path
 // fp32 weight [N][K] -> MX-fp8: e4m3 bytes [N][K] + block scales [K/128][N] (GemmParams::W_sc layout); K % 128 == 0
-int launch_pack_fp8_weight(const float* src, uint8_t* w8, uint32_t* sc, int N, int K, hipStream_t stream);
+// sc row n of this call is column n0 + n of a scale array with n_total columns (q, k, v packed into one [3D][D] weight)
+int launch_pack_fp8_weight(const float* src, uint8_t* w8, uint32_t* sc, int N, int K, int n_total, int n0, hipStream_t stream);
 int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, int ps, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -139,6 +139,41 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restr
     }
 }
 
+// LayerNorm with an MX-fp8 result (precision 2): lane `l` of vector k holds columns 4*(l + 64k) .. +3, so a 32-column
+// scale block is 8 consecutive lanes and a 128-column K-tile half a wave.  out_sc: [D/128][sc_ld] dwords, byte b of
+// dword (kt, row) = E8M0 scale of columns kt*128 + 32b .. +31 (the layout GemmParams::A_sc documents).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_f8_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, uint8_t* __restrict__ out8,
+                                                           uint32_t* __restrict__ out_sc, int sc_ld, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 y[NV];
+    ln_row<NV>(x + (size_t)row * ldx, gamma, beta, D, eps, lane, y);
+    const int nvec = D >> 2;
+    uint8_t* sc_bytes = reinterpret_cast<uint8_t*>(out_sc);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        const bool on = idx < nvec;
+        float a = on ? fmaxf(fmaxf(fabsf(y[k][0]), fabsf(y[k][1])), fmaxf(fabsf(y[k][2]), fabsf(y[k][3]))) : 0.f;
+        a = fmaxf(a, __shfl_xor(a, 1, 64));
+        a = fmaxf(a, __shfl_xor(a, 2, 64));
+        a = fmaxf(a, __shfl_xor(a, 4, 64));
+        const int sb = mx_scale_byte(a);
+        const float inv = mx_inv_scale(sb);
+        if (on) {
+            reinterpret_cast<unsigned*>(out8 + (size_t)row * D)[idx] =
+                cvt4_e4m3(y[k][0] * inv, y[k][1] * inv, y[k][2] * inv, y[k][3] * inv);
+            if ((lane & 7) == 0) {
+                const int col = idx * 4, kt = col >> 7, b = (col & 127) >> 5;
+                sc_bytes[((size_t)kt * sc_ld + row) * 4 + b] = (uint8_t)sb;
+            }
+        }
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void final_norm_cls_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ cls_f32,
@@ -175,13 +210,44 @@ __device__ __forceinline__ int v_off(int row, int col) {   // col in halves
     return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
 }
 
+// Store one query's 64 context values of head `hd` as MX-fp8.  A lane holds dims 16*dt + 4*g + r (dt, r = 0..3) of
+// ONE query, the four lanes g = 0..3 with equal (lane & 15) share the query: a 32-dim scale block is dt in {2b, 2b+1}
+// over those four lanes.  The head's 64 dims are blocks (hd & 1) * 2 + {0, 1} of K-tile hd >> 1.
+__device__ __forceinline__ void attn_store_f8(const f32x4 (&o)[4], float inv, uint8_t* out8, uint32_t* out_sc, int sc_ld,
+                                              size_t row, bool valid, int D, int hd, int g) {
+    int sb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        float a = 0.f;
+#pragma unroll
+        for (int dt = 2 * b; dt < 2 * b + 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a = fmaxf(a, fabsf(o[dt][r] * inv));
+        a = fmaxf(a, __shfl_xor(a, 16, 64));
+        a = fmaxf(a, __shfl_xor(a, 32, 64));
+        sb[b] = mx_scale_byte(a);
+    }
+    if (!valid) return;
+    uint8_t* orow = out8 + row * D + hd * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const float m = inv * mx_inv_scale(sb[dt >> 1]);
+        *reinterpret_cast<unsigned*>(orow + 16 * dt) = cvt4_e4m3(o[dt][0] * m, o[dt][1] * m, o[dt][2] * m, o[dt][3] * m);
+    }
+    if (g == 0)
+        *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(out_sc) + ((size_t)(hd >> 1) * sc_ld + row) * 4 + (hd & 1) * 2) =
+            (uint16_t)(sb[0] | (sb[1] << 8));
+}
+
 // NKT = key tiles held in LDS (even); NV = tiles that contain at least one real key when that is known
 // at compile time (T in ((NV-1)*16, NV*16]), 0 = decide per element at run time.  With NV fixed only the
 // ONE partial tile is masked (4 compares per lane, once) and fully padded tiles cost no MFMA; the
 // run-time form costs a compare+select per score because hipcc if-converts the tail test.
 template <int NKT, int NV>
 __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
-                                                                            f16* __restrict__ out, int T, int D, int n_heads) {
+                                                                            void* __restrict__ out_v, uint32_t* __restrict__ out_sc,
+                                                                            int sc_ld, int T, int D, int n_heads) {
+    f16* __restrict__ out = reinterpret_cast<f16*>(out_v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = NKT * 16;
     constexpr int NQK = NV ? NV : NKT;                 // key tiles that need S = K Q^T
@@ -308,7 +374,9 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
             for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt], pf[s2], o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (q < nq) {
+        if (out_sc) {                                   // MX-fp8 context (wave-uniform branch; full-frame mode only)
+            attn_store_f8(o, 1.0f / sum, reinterpret_cast<uint8_t*>(out_v), out_sc, sc_ld, (size_t)b * T + q, q < nq, D, hd, g);
+        } else if (q < nq) {
             const float inv = 1.0f / sum;
             f16* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
 #pragma unroll
@@ -331,7 +399,9 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
 // accumulators all belong to ONE query, so the rescale is a per-lane scalar.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
-                                                                  f16* __restrict__ out, int T, int D, int n_heads) {
+                                                                  void* __restrict__ out_v, uint32_t* __restrict__ out_sc, int sc_ld,
+                                                                  int T, int D, int n_heads) {
+    f16* __restrict__ out = reinterpret_cast<f16*>(out_v);
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];    // [buf][K|V][64 keys][128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / n_heads, hd = blockIdx.x - b * n_heads;
@@ -440,7 +510,9 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (q < nq) {
+    if (out_sc) {
+        if (wave_active) attn_store_f8(o, 1.0f / l, reinterpret_cast<uint8_t*>(out_v), out_sc, sc_ld, (size_t)b * T + q, q < nq, D, hd, g);
+    } else if (q < nq) {
         const float inv = 1.0f / l;
         f16* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
 #pragma unroll
@@ -453,7 +525,8 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
 }
 
 template <int NKT, int NV>
-int launch_attention_t(const f16* qkv, const f16* q_cls, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
+int launch_attention_t(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_sc, int sc_ld, int n, int T, int D, int n_heads,
+                       hipStream_t stream) {
     constexpr int lds = NKT * 16 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -467,7 +540,7 @@ int launch_attention_t(const f16* qkv, const f16* q_cls, f16* out, int n, int T,
     constexpr int maxw = 8;                  // measured: 13 waves x 1 tile (35 us) loses to 7 waves x 2 tiles (29.6 us) at T = 201
     const int nqt = (T + 15) / 16, rounds = (nqt + maxw - 1) / maxw;
     const int nwaves = q_cls ? 4 : (nqt + rounds - 1) / rounds;       // CLS mode: one query tile, 4 waves stage K/V
-    hipLaunchKernelGGL((attention_kernel<NKT, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, q_cls, out, T, D, n_heads);
+    hipLaunchKernelGGL((attention_kernel<NKT, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, q_cls, out, out_sc, sc_ld, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -481,6 +554,29 @@ __global__ void convert_f16_kernel(const float* __restrict__ src, f16* __restric
     const f16 h = (f16)v;
     hi[i] = h;
     if (lo) lo[i] = (f16)(v - (float)h);
+}
+
+// One thread per 32-element block of a [N][K] weight: E8M0 scale (no clipping) + 32 e4m3 bytes.
+__global__ void pack_fp8_weight_kernel(const float* __restrict__ src, uint8_t* __restrict__ w8, uint32_t* __restrict__ sc,
+                                       int N, int K, int n_total, int n0) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kb_per_row = K / 32;
+    if (gid >= (int64_t)N * kb_per_row) return;
+    const int n = (int)(gid / kb_per_row), kb = (int)(gid - (int64_t)n * kb_per_row);
+    const float* p = src + (size_t)n * K + kb * 32;
+    f32x4 v[8];
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = reinterpret_cast<const f32x4*>(p)[i];
+        a = fmaxf(a, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
+    }
+    const int sb = mx_scale_byte(a);
+    const float inv = mx_inv_scale(sb);
+    unsigned* o = reinterpret_cast<unsigned*>(w8 + (size_t)n * K + kb * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = cvt4_e4m3(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
+    reinterpret_cast<uint8_t*>(sc)[((size_t)(kb >> 2) * n_total + n0 + n) * 4 + (kb & 3)] = (uint8_t)sb;
 }
 
 // w: (D,3,ps,ps).  hi/lo: (D,256) with the 16x16 slot layout (zero where i >= ps or j >= ps);
@@ -546,6 +642,20 @@ int launch_layernorm_f16(const float* x, int64_t ldx, const float* gamma, const 
     return CHECK_LAUNCH();
 }
 
+int launch_layernorm_f8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* out8,
+                        uint32_t* out_sc, int sc_ld, int M, int D, float eps, hipStream_t stream) {
+    if (D % 128) return -1;
+    const int nv = (D / 4 + 63) / 64;
+    const dim3 grid((M + 3) / 4), block(256);
+    switch (nv) {
+        case 2: hipLaunchKernelGGL(layernorm_f8_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, out8, out_sc, sc_ld, M, D, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_f8_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, out8, out_sc, sc_ld, M, D, eps); break;
+        case 4: hipLaunchKernelGGL(layernorm_f8_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, out8, out_sc, sc_ld, M, D, eps); break;
+        default: return -1;
+    }
+    return CHECK_LAUNCH();
+}
+
 int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
                           f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream) {
     const int nv = (D / 4 + 63) / 64;
@@ -560,24 +670,34 @@ int launch_final_norm_cls(const float* x, const float* gamma, const float* beta,
     return CHECK_LAUNCH();
 }
 
-int launch_attention(const f16* qkv, const f16* q_cls, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
+int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_sc, int sc_ld, int n, int T, int D, int n_heads,
+                     hipStream_t stream) {
+    if (q_cls && out_sc) return -1;                 // the CLS tail of the last layer stays fp16
     const int nkt = (T + 15) / 16;
     // exact-tile-count instantiations for the sequence lengths CBAS produces: 224x224 /16 -> T = 201 (13 tiles),
     // 256x256 /16 and 224x224 /14 -> T = 261 (17 tiles); everything else takes the run-time-masked form
-    if (nkt == 13) return launch_attention_t<14, 13>(qkv, q_cls, out, n, T, D, n_heads, stream);
-    if (nkt == 17) return launch_attention_t<18, 17>(qkv, q_cls, out, n, T, D, n_heads, stream);
-    if (nkt <= 2) return launch_attention_t<2, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
-    if (nkt <= 6) return launch_attention_t<6, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
-    if (nkt <= 14) return launch_attention_t<14, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
-    if (nkt <= 18) return launch_attention_t<18, 0>(qkv, q_cls, out, n, T, D, n_heads, stream);
+    if (nkt == 13) return launch_attention_t<14, 13>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt == 17) return launch_attention_t<18, 17>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 2) return launch_attention_t<2, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 6) return launch_attention_t<6, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 14) return launch_attention_t<14, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 18) return launch_attention_t<18, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
     // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
     const int nqb = q_cls ? 1 : ((T + 15) / 16 + 7) / 8;
-    hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, T, D, n_heads);
+    hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_convert_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(convert_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, hi, lo, n);
+    return CHECK_LAUNCH();
+}
+
+int launch_pack_fp8_weight(const float* src, uint8_t* w8, uint32_t* sc, int N, int K, int n_total, int n0, hipStream_t stream) {
+    if (K % 128) return -1;
+    const int64_t blocks = (int64_t)N * (K / 32);
+    hipLaunchKernelGGL(pack_fp8_weight_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, src, w8, sc, N, K,
+                       n_total, n0);
     return CHECK_LAUNCH();
 }
 

@@ -71,8 +71,15 @@ typedef struct cbas_enc_config {
     int32_t max_batch;            /* frames per encoder pass (workspace size)  */
     int32_t max_height;           /* largest frame the workspace must hold     */
     int32_t max_width;
-    int32_t precision;            /* 0: fp16 operands, fp32 accumulate/residual (default)
-                                     1: fp16 hi+lo split weights (2 MFMA/k-step) */
+    int32_t precision;            /* 0: fp16 operands, fp32 accumulate/residual (default; meets the 1e-3 CLS bar)
+                                     1: fp16 hi+lo split weights (2 MFMA/k-step)
+                                     2: MX-fp8 throughput mode (BASELINE.json configs[4]): the QKV / o_proj / up / down
+                                        GEMMs take e4m3 operands with one E8M0 scale per 32 k-elements - weights packed
+                                        at create, activations quantised by the producing kernels (LayerNorm,
+                                        attention, GELU epilogue) - on v_mfma_scale_f32_16x16x128_f8f6f4; accumulation,
+                                        residual stream, attention, patch embedding and the CLS tail of the last
+                                        layer are unchanged.  CLS error is a few 1e-2: held to label parity only.
+                                        hidden_size and intermediate_size must be multiples of 256. */
     int32_t use_rope;             /* 1: DINOv3 (RoPE on patch rows, no additive position embedding)     */
     int32_t pos_embed_grid;       /* G > 0: DINOv2-with-registers, learned (1+G*G, D) position embedding,
                                      bicubic-antialias interpolated to each frame's patch grid; else 0 */
@@ -163,6 +170,14 @@ int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes)
  * position-weighted checksum of the fp16 output, so tile variants can be compared bit for bit. */
 int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
                           unsigned long long* checksum_out);
+
+/* Bring-up / tests: the MX-fp8 GEMM of precision 2 in isolation.  A (M x K) and W (N x K) fp32 host matrices are
+ * quantised with the library's block quantiser (e4m3 elements, one E8M0 scale per 32 k-elements), multiplied by the
+ * fp8 kernel (tile: 0 = the shape's default, 13..16 = a fixed ping-pong tile) and out = A_q W_q^T (M x N fp32) is
+ * returned together with the quantised bytes and scales ([K/128][round_up(M,256)] resp. [K/128][N] dwords, byte b of
+ * a dword = block b of that 128-wide K-tile).  N % 256 == 0, K % 256 == 0. */
+int cbas_debug_gemm_f8(int M, int N, int K, int tile, const float* A_host, const float* W_host, float* out_host,
+                       uint8_t* A8_host, uint32_t* Asc_host, uint8_t* W8_host, uint32_t* Wsc_host);
 
 /* Per-kernel timing for benchmarks: while enabled, every kernel launch of the forward pass is
  * bracketed by HIP events on the launch stream.  cbas_enc_profile_read synchronises the device
