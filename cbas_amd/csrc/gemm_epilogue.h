@@ -81,11 +81,16 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
 // global access is whole 128-byte (fp16) / 256-byte (fp32) row segments.
 //   scratch: 8 KiB per wave, 16-byte aligned, wave-private (in-order LDS => no barrier needed).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int TM>
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
+// `pre` is called once, after the epilogue's first global loads have been issued (they would otherwise queue behind
+// it): the persistent kernel issues the next tile's first LDS-DMAs there.
+template <int EPI, int TM, typename Pre = NoPrefetch>
 __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_base, int head_col0, int lane,
-                                                   const f32x4 (&acc)[TM][4], char* scratch) {
+                                                   const f32x4 (&acc)[TM][4], char* scratch, Pre pre = Pre()) {
     const int li = lane & 15, g = lane >> 4;
     if (EPI == EPI_PATCH) {                      // small GEMM with a row scatter: keep the direct form
+        pre();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = row_base + i * 16 + li;
@@ -109,6 +114,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
         };
         load_x(0, xs[0]);
         if (TM > 1) load_x(1, xs[1]);
+        pre();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             char* sc = scratch + (i & 1) * 4096;
@@ -136,6 +142,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
         for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + head_col0 + j * 16 + g * 4);
         const int sec = (EPI == EPI_QKV) ? head_col0 / p.D + p.sec0 : 2;
         const float qs = (sec == 0) ? 0.125f : 1.0f;
+        pre();
 #pragma unroll
         for (int half = 0; half < (TM + 3) / 4; ++half) {              // up to 64 rows per pass (8 KiB of scratch)
 #pragma unroll

@@ -53,73 +53,97 @@ namespace {
 constexpr int BK = 64;
 constexpr int BN = 256;
 
-struct PPGrid {               // block -> tile map of one launch
-    int main_blocks;          // blocks [0, main_blocks): main tiles over rows [0, tail_row0)
+struct PPGrid {               // tile ids of one launch; workgroup b runs ids b, b + gridDim.x, b + 2 gridDim.x, ...
+    int main_blocks;          // ids [0, main_blocks): main tiles over rows [0, tail_row0)
     int tail_row0;            // first row of the tail segment (== M rounded up when there is none)
+    int n_tiles;              // ids [main_blocks, n_tiles): 128-row tail tiles
 };
 
 __device__ __forceinline__ f16x8 read_frag8(const char* lds_tile, int off) {
     return *reinterpret_cast<const f16x8*>(lds_tile + off);
 }
 
+// LDS bytes of a (TA, TB) tile: two staging buffers, with the epilogue's 64 KiB of per-wave scratch laid over
+// buffer 1 and whatever follows it (buffer 0 is being refilled with the next tile's first K-tile by then)
+template <int TA, int TB>
+constexpr int pp_lds_main() {
+    constexpr int buf = (32 * (TA + TB) + BN) * 128;
+    return 2 * buf > buf + 65536 ? 2 * buf : buf + 65536;
+}
+
+// Runs the tiles `first, first + stride, ...` (< n_kind) of one kind: tile id -> (tm, tn) through the XCD remap over
+// n_kind ids; rows start at base_row.  Persistent: while a tile's epilogue runs, the LDS-DMA of the NEXT tile's first
+// K-tile is already in flight into buffer 0 (its latency - most of the prologue - hides under the epilogue).
 template <int EPI, int TA, int TB, bool F8>
-__device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0, char* smem) {
+__device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int first, int n_kind, int stride, int base_row,
+                                         int tiles_n) {
     constexpr int TM = TA + TB;                      // 16-row MFMA tiles per wave
     constexpr int WROWS = 16 * TM;                   // rows of C per wave
     constexpr int BM = 2 * WROWS;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int TMAX = TA > TB ? TA : TB;
+    int row0 = 0, col0 = 0;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    // `lane` is laundered through an empty asm at the top of every tile and again before the next tile's offsets are
+    // formed: everything derived from it (staging / fragment offsets, ~20 VGPRs) is then recomputed per tile instead
+    // of being kept alive across the epilogue, which needs those registers (128 accumulators + 32 prefetched x values)
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int nk = p.K / (F8 ? 2 * BK : BK);           // even, >= 2 (checked by the launcher)
     constexpr int ESZ = F8 ? 1 : 2;                    // bytes per operand element: a K-tile is always 128 bytes per row
     const char* Abase = F8 ? reinterpret_cast<const char*>(p.A8) : reinterpret_cast<const char*>(p.A);
     const char* Wbase = F8 ? reinterpret_cast<const char*>(p.W8) : reinterpret_cast<const char*>(p.W);
-    char* const sc_lds = smem + 2 * BUF_BYTES;         // F8: [buf][A rows 256 x 4 B | B rows 256 x 4 B]
+    char* const sc_lds = smem + pp_lds_main<TA, TB>(); // F8: [buf][A rows 256 x 4 B | B rows 256 x 4 B]
 
     // ---- LDS-DMA source offsets: two 8-row pieces per wave and sub-tile --------------------------
     // A-sub0 = rows {wr' * WROWS + [0, 16 TA)}, A-sub1 = rows {wr' * WROWS + 16 TA + [0, 16 TB)}, wr' = 0,1;
     // B-sub h = rows with bit 5 == h.  Piece q of a sub-tile (q = wave, wave + 8); a sub-tile with fewer
     // than 16 pieces clamps q: the duplicates rewrite identical bytes (keeps the per-wave DMA count, and
     // so the vmcnt immediates, uniform)
-    const int lrow = lane >> 3;
     int a_lds[2][2], b_lds[2][2];
     unsigned a_src[2][2], b_src[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int T = h ? TB : TA;
-            int q = wave + 8 * s;
-            q = q < 4 * T ? q : 4 * T - 1;
-            const int ar = (q / (2 * T)) * WROWS + h * (16 * TA) + (q % (2 * T)) * 8;   // first row of the piece
-            a_lds[h][s] = ar * 128;
-            const int r = ar + lrow;
-            int grow = row0 + r;
-            grow = grow < p.M_pad - 1 ? grow : p.M_pad - 1;
-            a_src[h][s] = (unsigned)grow * (unsigned)(p.lda * ESZ) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);     // bytes
-            const int qb = wave + 8 * s;
-            const int br = (((qb >> 2) << 3) | (h << 2) | (qb & 3)) * 8;
-            b_lds[h][s] = A_BYTES + br * 128;
-            const int rb = br + lrow;
-            b_src[h][s] = (unsigned)(col0 + rb) * (unsigned)(p.K * ESZ) + (((lane & 7) ^ ((rb >> 1) & 7)) << 4);
-        }
     // F8: block scales of one K-tile.  Waves 0-3 fetch the dwords of A rows row0 + 64*wave + lane, waves 4-7 those of
     // W rows col0 + 64*(wave-4) + lane (rows past the tile / past M_pad are clamped or belong to a neighbour: never used)
     const uint32_t* sc_src = nullptr;
-    int sc_step = 0, sc_dst = 0;
-    if (F8) {
-        if (wave < 4) {
-            int r = row0 + wave * 64 + lane;
-            r = r < p.M_pad - 1 ? r : p.M_pad - 1;
-            sc_src = p.A_sc + r; sc_step = p.sc_lda;
-        } else {
-            sc_src = p.W_sc + col0 + (wave - 4) * 64 + lane; sc_step = p.sc_ldw ? p.sc_ldw : p.N;
+    const int sc_step = F8 ? (wave < 4 ? p.sc_lda : (p.sc_ldw ? p.sc_ldw : p.N)) : 0, sc_dst = wave * 256;
+    auto set_tile = [&](int id) {
+        const int lrow = lane >> 3;
+        const int bid = gemm_xcd_remap(id, n_kind);
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        row0 = base_row + tm * BM;
+        col0 = tn * BN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int T = h ? TB : TA;
+                int q = wave + 8 * s;
+                q = q < 4 * T ? q : 4 * T - 1;
+                const int ar = (q / (2 * T)) * WROWS + h * (16 * TA) + (q % (2 * T)) * 8;   // first row of the piece
+                a_lds[h][s] = ar * 128;
+                const int r = ar + lrow;
+                int grow = row0 + r;
+                grow = grow < p.M_pad - 1 ? grow : p.M_pad - 1;
+                a_src[h][s] = (unsigned)grow * (unsigned)(p.lda * ESZ) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);     // bytes
+                const int qb = wave + 8 * s;
+                const int br = (((qb >> 2) << 3) | (h << 2) | (qb & 3)) * 8;
+                b_lds[h][s] = A_BYTES + br * 128;
+                const int rb = br + lrow;
+                b_src[h][s] = (unsigned)(col0 + rb) * (unsigned)(p.K * ESZ) + (((lane & 7) ^ ((rb >> 1) & 7)) << 4);
+            }
+        if (F8) {
+            if (wave < 4) {
+                int r = row0 + wave * 64 + lane;
+                r = r < p.M_pad - 1 ? r : p.M_pad - 1;
+                sc_src = p.A_sc + r;
+            } else {
+                sc_src = p.W_sc + col0 + (wave - 4) * 64 + lane;
+            }
         }
-        sc_dst = wave * 256;
-    }
+    };
+    set_tile(first);
     // which: 0 = B-sub0, 1 = A-sub0, 2 = B-sub1, 3 = A-sub1 (the issue order within a K-tile)
     auto stage = [&](int buf, int kt, int which) {
         char* base = smem + buf * BUF_BYTES;
@@ -138,35 +162,24 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
     };
 
     // ---- fragment read offsets (swizzled 128-B rows, as gemm_f16.hip) -------------------------------
-    const int frow = lane & 15, fchunk = lane >> 4;
     int a_off[2], b_off[2];                           // per k-half; + row-block immediates
+    int sa_off = 0, sb_off = 0;                       // F8: byte of lane (frow, q = fchunk) in the scale image: row * 4 + q
+    auto set_frag_offsets = [&] {
+        const int frow = lane & 15, fchunk = lane >> 4;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int sw = ((kk * 4 + fchunk) ^ ((frow >> 1) & 7)) << 4;
-        a_off[kk] = (wr * WROWS + frow) * 128 + sw;
-        b_off[kk] = A_BYTES + (wc * 64 + frow) * 128 + sw;
-    }
-
-    // F8: byte of lane (frow, q = fchunk) in the scale image: row * 4 + q
-    const int sa_off = (wr * WROWS + frow) * 4 + fchunk;              // + (I0 + i) * 64
-    const int sb_off = 1024 + (wc * 64 + frow) * 4 + fchunk;          // + (h * 2 + j) * 64
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw = ((kk * 4 + fchunk) ^ ((frow >> 1) & 7)) << 4;
+            a_off[kk] = (wr * WROWS + frow) * 128 + sw;
+            b_off[kk] = A_BYTES + (wc * 64 + frow) * 128 + sw;
+        }
+        sa_off = (wr * WROWS + frow) * 4 + fchunk;              // + (I0 + i) * 64
+        sb_off = 1024 + (wc * 64 + frow) * 4 + fchunk;          // + (h * 2 + j) * 64
+    };
 
     f32x4 acc[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
     if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
-
-    // ---- prologue: K-tile 0 and three sub-tiles of K-tile 1 ------------------------------------
-    stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3);
-    stage(1, 1, 0); stage(1, 1, 1); stage(1, 1, 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
+    stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3);      // K-tile 0 of the first tile
 
     // fragments: fp16 form = two 16-byte k-halves per 16-row tile; F8 form = the same two reads joined into the
     // 8-register operand of the scaled MFMA (a register sequence, no copies) + its E8M0 scale byte
@@ -276,20 +289,52 @@ __device__ __forceinline__ void pp_tile(const GemmParams& p, int row0, int col0,
         CBAS_SEG_BARRIER();
     };
 
-    for (int t = 0; t < nk; t += 2) {
-        ktile(0, t);
-        ktile(1, t + 1);
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the groups: every wave has now left the loop
-#undef CBAS_SEG_BARRIER
+    for (int id = first;;) {
+        asm volatile("" : "+v"(lane));
+        set_tile(id);                                     // same values the K-tile 0 staging used; see `lane` above
+        set_frag_offsets();
+        // ---- rest of the prologue: K-tile 0 is in flight (issued above, or under the previous tile's epilogue);
+        // three sub-tiles of K-tile 1 follow.  vmcnt counts in issue order, so vmcnt(6) also retires every store of
+        // the previous tile's epilogue.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage(1, 1, 0); stage(1, 1, 1); stage(1, 1, 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.stamps && id == first) t_pro = __builtin_amdgcn_s_memtime();
+        if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
 
-    if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
-    gemm_epilogue_tile<EPI, TM>(p, row0 + wr * WROWS, col0 + wc * 64, lane, acc, smem + wave * 8192);
-    if (p.stamps && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
-        o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
+        for (int t = 0; t < nk; t += 2) {
+            ktile(0, t);
+            ktile(1, t + 1);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the groups: every wave has now left the loop
+
+        if (p.stamps && id == first) t_loop = __builtin_amdgcn_s_memtime();
+        const int erow = row0 + wr * WROWS, ecol = col0 + wc * 64;
+        const int next = id + stride;
+        const bool has_next = next < n_kind;
+        asm volatile("" : "+v"(lane));
+        if (has_next) set_tile(next);                     // the staging offsets now describe the NEXT tile
+        // every wave is past the loop: buffer 0 is free, and the scratch below lies over buffer 1
+        gemm_epilogue_tile<EPI, TM>(p, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
+            if (has_next) { stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
+        });
+        if (p.stamps && id == first && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+            o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
+        }
+        if (!has_next) break;
+        id = next;
+        // the next prologue refills buffer 1: every wave must be done with its scratch (raw barrier: the K-tile 0
+        // LDS-DMA stays in flight across it)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
+#undef CBAS_SEG_BARRIER
 }
 
 // TAIL = 1: blocks past g.main_blocks run 128x256 tiles over rows [g.tail_row0, M)
@@ -297,23 +342,34 @@ template <int EPI, int TA, int TB, int TAIL, bool F8>
 __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGrid g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N / BN;
-    if (!TAIL || (int)blockIdx.x < g.main_blocks) {
-        const int bid = gemm_xcd_remap(blockIdx.x, TAIL ? g.main_blocks : (int)gridDim.x);
-        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-        pp_tile<EPI, TA, TB, F8>(p, tm * 32 * (TA + TB), tn * BN, smem);
-    } else {
-        const int bid = gemm_xcd_remap(blockIdx.x - g.main_blocks, gridDim.x - g.main_blocks);
-        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-        pp_tile<EPI, 2, 2, F8>(p, g.tail_row0 + tm * 128, tn * BN, smem);
+    const int G = gridDim.x;                                   // a multiple of 8 whenever a workgroup gets > 1 tile
+    int first = blockIdx.x;
+    if (first < g.main_blocks) {
+        pp_tiles<EPI, TA, TB, F8>(p, smem, first, g.main_blocks, G, 0, tiles_n);
+        first += ((g.main_blocks - 1 - first) / G + 1) * G;    // this workgroup's first id past the main tiles
     }
+    if (TAIL && first < g.n_tiles) {
+        // the first tail tile's K-tile 0 is not prefetched across the kind switch: drain the LDS before restaging
+        __syncthreads();
+        pp_tiles<EPI, 2, 2, F8>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n);
+    }
+}
+
+int pp_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
 }
 
 template <int EPI, int TA, int TB, int TAIL, bool F8>
 int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     constexpr int BM = 32 * (TA + TB);
-    constexpr int lds = 2 * (BM * 128 + BN * 128) + (F8 ? 4096 : 0);
+    constexpr int lds_main = TAIL && pp_lds_main<2, 2>() > pp_lds_main<TA, TB>() ? pp_lds_main<2, 2>() : pp_lds_main<TA, TB>();
+    constexpr int lds = lds_main + (F8 ? 4096 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static_assert(lds >= 8 * 8192 && 2 * (128 * 128 + BN * 128) >= 8 * 8192, "epilogue scratch");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>),
@@ -323,17 +379,21 @@ int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     }
     const int tiles_n = p.N / BN;
     PPGrid g;
-    int grid;
     if (TAIL) {
         g.main_blocks = main_panels * tiles_n;
         g.tail_row0 = main_panels * BM;
         if (g.tail_row0 >= p.M) return -1;
-        grid = g.main_blocks + ((p.M - g.tail_row0 + 127) / 128) * tiles_n;
+        g.n_tiles = g.main_blocks + ((p.M - g.tail_row0 + 127) / 128) * tiles_n;
     } else {
-        grid = ((p.M + BM - 1) / BM) * tiles_n;
-        g.main_blocks = grid;
+        g.n_tiles = ((p.M + BM - 1) / BM) * tiles_n;
+        g.main_blocks = g.n_tiles;
         g.tail_row0 = p.M;
     }
+    // persistent: one workgroup per CU walks the tile ids with a stride of the grid size (a multiple of 8, so a
+    // workgroup's tiles stay in its XCD's contiguous range of the remap)
+    static const int persist = [] { const char* e = getenv("CBAS_PP_PERSIST"); return e ? atoi(e) : 1; }();
+    const int slots = pp_cus() & ~7;
+    const int grid = persist && g.n_tiles > slots ? slots : g.n_tiles;
     hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>), dim3(grid), dim3(512), lds, stream, p, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
