@@ -28,7 +28,8 @@ class EncConfig(C.Structure):
 class HeadConfigC(C.Structure):
     _fields_ = [("in_features", c_int32), ("out_features", c_int32), ("seq_len", c_int32),
                 ("bottleneck_dim", c_int32), ("lin0_dim", c_int32), ("lstm_hidden_size", c_int32),
-                ("center_window_size", c_int32), ("ema_alpha", c_float), ("lstm_layers", c_int32)]
+                ("center_window_size", c_int32), ("ema_alpha", c_float), ("lstm_layers", c_int32),
+                ("use_acceleration", c_int32)]
 
 
 class TrainConfigC(C.Structure):

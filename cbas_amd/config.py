@@ -168,8 +168,8 @@ class HeadConfig:
     def validate(self) -> None:
         if not 1 <= self.lstm_layers <= 4:
             raise NotImplementedError("lstm_layers must be in [1, 4]")
-        if not self.use_acceleration:
-            raise NotImplementedError("use_acceleration=False is not implemented")
+        if self.lstm_hidden_size < 16 or self.lstm_hidden_size > 128 or self.lstm_hidden_size % 16:
+            raise NotImplementedError("lstm_hidden_size must be a multiple of 16 in [16, 128]")
         if self.seq_len < 3:
             raise NotImplementedError("seq_len < 3 (replicate-pad delta mode) is not implemented")
         if self.centre_lo >= self.centre_hi:

@@ -34,7 +34,8 @@ int64_t head_weights_count(const cbas_head_config& c) {
     const int64_t I = c.in_features, C = c.out_features, Bn = c.bottleneck_dim, L0 = c.lin0_dim, h = c.lstm_hidden_size;
     int64_t lstm = 0;
     for (int l = 0; l < c.lstm_layers; ++l) lstm += 2 * (4 * h * (l == 0 ? L0 : 2 * h) + 4 * h * h + 8 * h);
-    return 2 + 3 * (Bn * I + Bn) + 3 * 2 * Bn + (L0 * 3 * Bn + L0) + (C * I + C) + lstm + (2 * h + 1) + (C * 2 * h + C);
+    const int64_t NS = c.use_acceleration ? 3 : 2;
+    return 2 + NS * (Bn * I + Bn) + NS * 2 * Bn + (L0 * NS * Bn + L0) + (C * I + C) + lstm + (2 * h + 1) + (C * 2 * h + C);
 }
 
 // One chunk of windows through expand -> lin0 -> centre -> in-proj -> recurrent -> pool.
@@ -44,8 +45,8 @@ int run_chunk(cbas_head* h, int64_t nw, int sliding, int64_t w0, int64_t r0, int
     LAUNCH_TRY(launch_head_expand(h->proj, d, h->b_bott, h->ln_w, h->ln_b, h->b_lin1, nw, sliding, w0, r0, n_frames,
                                   h->aug, h->lin_logits, st));
     Gemm32Params g{};
-    g.A = h->aug; g.lda = 3 * d.Bn; g.W = h->w_lin0; g.bias = h->b_lin0; g.out = h->xl; g.ldo = d.L0;
-    g.M = nw * d.T; g.N = d.L0; g.N_alloc = d.L0; g.K = 3 * d.Bn;
+    g.A = h->aug; g.lda = d.NS * d.Bn; g.W = h->w_lin0; g.bias = h->b_lin0; g.out = h->xl; g.ldo = d.L0;
+    g.M = nw * d.T; g.N = d.L0; g.N_alloc = d.L0; g.K = d.NS * d.Bn;
     LAUNCH_TRY(launch_gemm_f32(g, 1, st));
     LAUNCH_TRY(launch_head_centre(h->xl, nw, d.T, d.L0, st));
     for (int l = 0; l < h->n_layers; ++l) {
@@ -102,9 +103,11 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     const int T = c.seq_len;
     if (I <= 0 || I % 32) return cbas_fail(CBAS_EINVAL, "in_features=%lld must be a positive multiple of 32", (long long)I);
     if (C <= 0 || C > 64) return cbas_fail(CBAS_EINVAL, "out_features=%lld outside [1,64]", (long long)C);
-    if (Bn % 64 || Bn <= 0 || Bn > 256 || (3 * Bn) % 32) return cbas_fail(CBAS_EINVAL, "bottleneck_dim=%lld unsupported", (long long)Bn);
+    const int64_t NS = c.use_acceleration ? 3 : 2;       // bottleneck streams (classifier_head.py:74-84,158-162)
+    if (Bn % 64 || Bn <= 0 || Bn > 256 || (NS * Bn) % 32) return cbas_fail(CBAS_EINVAL, "bottleneck_dim=%lld unsupported", (long long)Bn);
     if (L0 % 32 || L0 <= 0) return cbas_fail(CBAS_EINVAL, "lin0_dim=%lld must be a multiple of 32", (long long)L0);
-    if (hh != 64 && hh != 128) return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%lld: only 64 and 128 are built", (long long)hh);
+    if (hh < 16 || hh > 128 || hh % 16)
+        return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%lld: multiples of 16 up to 128 are built", (long long)hh);
     if (T < 3 || T > 101) return cbas_fail(CBAS_EINVAL, "seq_len=%d outside [3,101]", T);
     if (c.lstm_layers < 1 || c.lstm_layers > 4) return cbas_fail(CBAS_EINVAL, "lstm_layers=%d outside [1,4]", c.lstm_layers);
     const int hsl = T / 2, sw = c.center_window_size;
@@ -120,7 +123,8 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     h->cfg = c; h->device = device_id;
     HeadDims& d = h->d;
     d.I = (int)I; d.C = (int)C; d.T = T; d.Bn = (int)Bn; d.L0 = (int)L0; d.h = (int)hh; d.lo = lo; d.hi = hi;
-    d.NPROJ = (int)round_up(3 * Bn + C, 4);
+    d.NS = (int)NS;
+    d.NPROJ = (int)round_up(NS * Bn + C, 4);
     d.alpha = c.ema_alpha;
 
     // ---- repack the state dict into the layouts the kernels read --------------------------------
@@ -128,10 +132,10 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     const float gate = p[0], att_temp_raw = p[1];
     p += 2;
     const float* bw[3]; const float* bb[3];
-    for (int s = 0; s < 3; ++s) { bw[s] = p; p += Bn * I; bb[s] = p; p += Bn; }
+    for (int s = 0; s < NS; ++s) { bw[s] = p; p += Bn * I; bb[s] = p; p += Bn; }
     const float* lnw[3]; const float* lnb[3];
-    for (int s = 0; s < 3; ++s) { lnw[s] = p; p += Bn; lnb[s] = p; p += Bn; }
-    const float* lin0_w = p; p += L0 * 3 * Bn;
+    for (int s = 0; s < NS; ++s) { lnw[s] = p; p += Bn; lnb[s] = p; p += Bn; }
+    const float* lin0_w = p; p += L0 * NS * Bn;
     const float* lin0_b = p; p += L0;
     const float* lin1_w = p; p += C * I;
     const float* lin1_b = p; p += C;
@@ -154,16 +158,16 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     std::vector<float> arena;
     auto put = [&](const float* src, int64_t n) { size_t o = arena.size(); arena.insert(arena.end(), src, src + n); return o; };
     auto pad4 = [&]() { while (arena.size() % 4) arena.push_back(0.f); };
-    // w_proj rows: cls | delta | acc | lin1 | zero rows up to NPROJ
+    // w_proj rows: cls | delta | (acc) | lin1 | zero rows up to NPROJ
     const size_t o_proj = arena.size();
-    for (int s = 0; s < 3; ++s) put(bw[s], Bn * I);
+    for (int s = 0; s < NS; ++s) put(bw[s], Bn * I);
     put(lin1_w, C * I);
     arena.resize(o_proj + (size_t)d.NPROJ * I, 0.f);
-    const size_t o_bbott = arena.size(); for (int s = 0; s < 3; ++s) put(bb[s], Bn);
-    const size_t o_lnw = arena.size(); for (int s = 0; s < 3; ++s) put(lnw[s], Bn);
-    const size_t o_lnb = arena.size(); for (int s = 0; s < 3; ++s) put(lnb[s], Bn);
+    const size_t o_bbott = arena.size(); for (int s = 0; s < NS; ++s) put(bb[s], Bn);
+    const size_t o_lnw = arena.size(); for (int s = 0; s < NS; ++s) put(lnw[s], Bn);
+    const size_t o_lnb = arena.size(); for (int s = 0; s < NS; ++s) put(lnb[s], Bn);
     const size_t o_blin1 = put(lin1_b, C); pad4();
-    const size_t o_wlin0 = put(lin0_w, L0 * 3 * Bn);
+    const size_t o_wlin0 = put(lin0_w, L0 * NS * Bn);
     const size_t o_blin0 = put(lin0_b, L0); pad4();
     size_t o_wih[4], o_bgate[4], o_whh[4];
     for (int l = 0; l < NL; ++l) {
@@ -202,7 +206,7 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     h->proj_rows_cap = WCHUNK * T;       // explicit-window mode needs WCHUNK*T rows, sliding WCHUNK+T
     CREATE_TRY(hipMalloc(&h->rows32, (WCHUNK + T) * I * sizeof(float)));   // sliding mode: chunk + halo rows
     CREATE_TRY(hipMalloc(&h->proj, h->proj_rows_cap * d.NPROJ * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->aug, WCHUNK * T * 3 * Bn * sizeof(float)));
+    CREATE_TRY(hipMalloc(&h->aug, WCHUNK * T * NS * Bn * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->xl, WCHUNK * T * L0 * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->gin, WCHUNK * T * 8 * hh * sizeof(float)));
     CREATE_TRY(hipMalloc(&h->hout, WCHUNK * (hi - lo) * 2 * hh * sizeof(float)));

@@ -161,6 +161,7 @@ extern "C" int cbas_head_train_create(const cbas_head_config* cfg, const cbas_tr
     if (c.out_features <= 0 || c.out_features > 64) return cbas_fail(CBAS_EINVAL, "out_features=%d outside [1,64]", c.out_features);
     if (c.bottleneck_dim % 64 || c.bottleneck_dim <= 0 || c.bottleneck_dim > 256) return cbas_fail(CBAS_EINVAL, "bottleneck_dim=%d unsupported", c.bottleneck_dim);
     if (c.lin0_dim % 32 || c.lin0_dim <= 0) return cbas_fail(CBAS_EINVAL, "lin0_dim=%d must be a multiple of 32", c.lin0_dim);
+    if (!c.use_acceleration) return cbas_fail(CBAS_EINVAL, "training needs use_acceleration = 1 (three bottleneck streams)");
     if (c.lstm_hidden_size != 64 && c.lstm_hidden_size != 128) return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%d: only 64 and 128 are built", c.lstm_hidden_size);
     if (c.seq_len < 3 || c.seq_len > 101) return cbas_fail(CBAS_EINVAL, "seq_len=%d outside [3,101]", c.seq_len);
     if (c.lstm_layers < 1 || c.lstm_layers > 4) return cbas_fail(CBAS_EINVAL, "lstm_layers=%d outside [1,4]", c.lstm_layers);

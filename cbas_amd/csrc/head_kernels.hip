@@ -26,14 +26,14 @@ __global__ void f16_to_f32_kernel(const f16* __restrict__ src, float* __restrict
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------
-// expand: one workgroup (3*Bn threads) per window
+// expand: one workgroup (NS*Bn threads) per window; NS = 3 streams (cls, delta, acc) or 2 (use_acceleration = False)
 // ---------------------------------------------------------------------------------------------
 __global__ void head_expand_kernel(const float* __restrict__ proj, HeadDims d, const float* __restrict__ b_bott,
                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                    const float* __restrict__ b_lin1, int sliding, int64_t w0, int64_t r0,
                                    int64_t n_frames, float* __restrict__ aug, float* __restrict__ lin_logits) {
     extern __shared__ __attribute__((aligned(16))) float sbuf[];   // [T][3Bn]
-    const int W3 = 3 * d.Bn, T = d.T, half = T / 2;
+    const int W3 = d.NS * d.Bn, T = d.T, half = T / 2;
     const int tid = threadIdx.x;
     const int64_t w = blockIdx.x;
     const int stream = tid / d.Bn;
@@ -82,8 +82,8 @@ __global__ void head_expand_kernel(const float* __restrict__ proj, HeadDims d, c
     // pass 3: LayerNorm(Bn) per (t, stream) row, one wave per row
     const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int per = d.Bn >> 6;     // values per lane (Bn multiple of 64)
-    for (int r = wave; r < T * 3; r += nwaves) {
-        const int t = r / 3, st = r - t * 3;
+    for (int r = wave; r < T * d.NS; r += nwaves) {
+        const int t = r / d.NS, st = r - t * d.NS;
         const float* yrow = sbuf + t * W3 + st * d.Bn;
         float vals[4];
         float sum = 0.f;
@@ -198,37 +198,37 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= nw) return;
-    const int H2 = 2 * d.h, nc = d.hi - d.lo, per = H2 >> 6;     // H2 multiple of 64
+    const int H2 = 2 * d.h, nc = d.hi - d.lo, per = (H2 + 63) >> 6;   // lane holds columns lane + 64k < H2 (H2 <= 256)
     const float* hw = hout + w * nc * H2;
 
     float wa[4];
-    for (int k = 0; k < per; ++k) wa[k] = w_att[lane + 64 * k];
+    for (int k = 0; k < per; ++k) wa[k] = lane + 64 * k < H2 ? w_att[lane + 64 * k] : 0.f;
     // scores (two passes: max, then exp-sum and weighted latent)
     float mx = -INFINITY;
     for (int t = 0; t < nc; ++t) {
         float p = 0.f;
-        for (int k = 0; k < per; ++k) p += hw[t * H2 + lane + 64 * k] * wa[k];
+        for (int k = 0; k < per; ++k) p += (lane + 64 * k < H2 ? hw[t * H2 + lane + 64 * k] : 0.f) * wa[k];
         const float sc = (wave_sum(p) + b_att) / att_temp;
         mx = fmaxf(mx, sc);
     }
     float den = 0.f, lat[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nc; ++t) {
         float p = 0.f, hv[4];
-        for (int k = 0; k < per; ++k) { hv[k] = hw[t * H2 + lane + 64 * k]; p += hv[k] * wa[k]; }
+        for (int k = 0; k < per; ++k) { hv[k] = lane + 64 * k < H2 ? hw[t * H2 + lane + 64 * k] : 0.f; p += hv[k] * wa[k]; }
         const float e = expf((wave_sum(p) + b_att) / att_temp - mx);
         den += e;
         for (int k = 0; k < per; ++k) lat[k] += e * hv[k];
     }
     for (int k = 0; k < per; ++k) {
         lat[k] /= den;
-        if (latent) latent[w * H2 + lane + 64 * k] = lat[k];
+        if (latent && lane + 64 * k < H2) latent[w * H2 + lane + 64 * k] = lat[k];
     }
     // lin2, gate lerp, softmax over classes (every lane ends up holding every logit via wave_sum)
     const float tdiv = fmaxf(1e-3f, temperature);
     float mine = 0.f, zmax = -INFINITY;
     for (int cidx = 0; cidx < d.C; ++cidx) {
         float p = 0.f;
-        for (int k = 0; k < per; ++k) p += lat[k] * w_lin2[cidx * H2 + lane + 64 * k];
+        for (int k = 0; k < per; ++k) p += lane + 64 * k < H2 ? lat[k] * w_lin2[cidx * H2 + lane + 64 * k] : 0.f;
         const float lstm_logit = wave_sum(p) + b_lin2[cidx];
         const float lin = lin_logits[w * d.C + cidx];
         // torch.lerp(lin, lstm, g): g < 0.5 ? lin + g*(lstm-lin) : lstm - (lstm-lin)*(1-g)
@@ -260,8 +260,8 @@ int launch_f16_to_f32(const f16* src, float* dst, int64_t n, hipStream_t stream)
 int launch_head_expand(const float* proj, const HeadDims& d, const float* b_bott, const float* ln_w,
                        const float* ln_b, const float* b_lin1, int64_t n_windows, int sliding, int64_t w0,
                        int64_t r0, int64_t n_frames, float* aug, float* lin_logits, hipStream_t stream) {
-    const int threads = 3 * d.Bn;
-    if (d.Bn % 64 || threads > 1024 || d.Bn > 256 || d.C > threads || d.T < 3) return -1;
+    const int threads = d.NS * d.Bn;
+    if (d.Bn % 64 || threads > 1024 || d.Bn > 256 || d.C > threads || d.T < 3 || d.NS < 2 || d.NS > 3) return -1;
     const size_t lds = (size_t)d.T * threads * sizeof(float);
     if (lds > 160 * 1024) return -1;
     static bool attr_set = false;
@@ -284,12 +284,14 @@ int launch_head_centre(float* xl, int64_t n_windows, int T, int L0, hipStream_t 
 int launch_head_lstm(const float* gin, const float* w_hh, const HeadDims& d, int olo, int ohi, int64_t n_windows,
                      float* hout, hipStream_t stream) {
     const dim3 grid((unsigned)((n_windows + 15) / 16), 2);
-    if (d.h == 64)
-        hipLaunchKernelGGL(head_lstm_kernel<64>, grid, dim3(256), 0, stream, gin, w_hh, d.T, olo, ohi, n_windows, hout);
-    else if (d.h == 128)
-        hipLaunchKernelGGL(head_lstm_kernel<128>, grid, dim3(512), 0, stream, gin, w_hh, d.T, olo, ohi, n_windows, hout);
-    else
-        return -1;
+    // one wave per 16 hidden units: any multiple of 16 up to 128 (W_hh fragments are H registers per lane)
+#define CBAS_LSTM_CASE(H) case H: hipLaunchKernelGGL(head_lstm_kernel<H>, grid, dim3(4 * H), 0, stream, gin, w_hh, d.T, olo, ohi, n_windows, hout); break;
+    switch (d.h) {
+        CBAS_LSTM_CASE(16) CBAS_LSTM_CASE(32) CBAS_LSTM_CASE(48) CBAS_LSTM_CASE(64) CBAS_LSTM_CASE(80) CBAS_LSTM_CASE(96)
+        CBAS_LSTM_CASE(112) CBAS_LSTM_CASE(128)
+        default: return -1;
+    }
+#undef CBAS_LSTM_CASE
     return CHECK_LAUNCH();
 }
 
@@ -297,7 +299,7 @@ int launch_head_pool(const float* hout, const float* lin_logits, const HeadDims&
                      float b_att, float att_temp, const float* w_lin2, const float* b_lin2, float gate_sigmoid,
                      float temperature, int64_t n_windows, float* probs, float* logits, float* latent,
                      hipStream_t stream) {
-    if (d.C > 64 || (2 * d.h) % 64 || 2 * d.h > 256) return -1;
+    if (d.C > 64 || 2 * d.h > 256) return -1;
     hipLaunchKernelGGL(head_pool_kernel, dim3((unsigned)((n_windows + 3) / 4)), dim3(256), 0, stream, hout, lin_logits,
                        d, w_att, b_att, att_temp, w_lin2, b_lin2, gate_sigmoid, temperature, n_windows, probs, logits,
                        latent);

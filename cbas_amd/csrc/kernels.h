@@ -127,8 +127,9 @@ int launch_splitk_reduce(const float* partial, int splits, int64_t stride, int64
 
 struct HeadDims {
     int I, C, T, Bn, L0, h;   // in_features, classes, seq_len, bottleneck dim, lin0 dim, lstm hidden
+    int NS;                   // bottleneck streams: 3 (cls, delta, acc) or 2 when use_acceleration = False
     int lo, hi;               // centre window [lo, hi) in window time
-    int NPROJ;                // projection width: 3*Bn + C rounded up to a multiple of 4
+    int NPROJ;                // projection width: NS*Bn + C rounded up to a multiple of 4
     float alpha;
 };
 

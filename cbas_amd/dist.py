@@ -1,10 +1,14 @@
 """Multi-GPU: one process per GPU, clips sharded across ranks, outputs gathered to rank 0.
 
-The reference has no distributed code at all; the path shards naturally by clip
-(each video is encoded and classified independently), so ranks never exchange data on the hot
-path.  The only collective is the end-of-clip *gather* of the output rows — (N_i, D) fp16 CLS and
-(N_i, C) fp32 probabilities — to the rank that writes the ``_cls.h5`` / ``_outputs.csv`` files.
-On MI355X that is RCCL over xGMI (``backend="nccl"``); the CPU tests use ``gloo``.
+The reference has no distributed code at all: its EncodeThread drains ONE queue of videos on ONE
+device (backend/workthreads.py:276-348).  The path shards naturally by clip (each video is encoded and classified
+independently), so ranks never exchange data on the hot path.  The only exchange is the end-of-clip *gather* of the
+output rows - (N_i, D) fp16 CLS and (N_i, C) fp32 probabilities - to the rank that writes the ``_cls.h5`` /
+``_outputs.csv`` files: grouped point-to-point sends (``batch_isend_irecv`` = one ncclGroupStart/End on RCCL), so
+every peer uses its own xGMI link to rank 0 and no rank receives rows it does not need.  On MI355X that is RCCL
+(``backend="nccl"``); the CPU tests use ``gloo``.
+
+``encode_files`` is the product entry point: what the reference's queue does for a list of videos, on N GPUs.
 """
 from __future__ import annotations
 
@@ -23,6 +27,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL exchanges device buffers between the ranks' processes through HIP IPC handles; this pool's host driver
+        # only supports the dmabuf form, and with the legacy mode RCCL fails in hipIpcGetMemHandle (invalid argument)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -42,62 +48,146 @@ def owner_of(clip: int, world: int) -> int:
 
 
 def gather_rows(local: Sequence[torch.Tensor], dst: int = 0) -> Optional[List[List[torch.Tensor]]]:
-    """Variable-length gather.  ``local`` is this rank's list of 2-D tensors (one per local clip,
-    all with the same trailing dim and dtype across ranks).  Returns on ``dst`` a list over ranks
-    of lists of tensors (on the same device as the inputs); ``None`` elsewhere.
+    """Variable-length gather to ``dst``.  ``local`` is this rank's list of 2-D tensors (one per local clip, all with
+    the same trailing dim and dtype across ranks).  Returns on ``dst`` a list over ranks of lists of tensors (on the
+    same device as the inputs); ``None`` elsewhere.
 
-    Collectives: all_gathers of the clip counts / row counts / dtype code, then one padded all_gather of
-    the concatenated rows (payloads are a few tens of MB per 30-minute clip; every
-    GPU has its own xGMI link to every peer, so the exchange is link-parallel)."""
+    Two steps: (1) a small all_gather of the per-clip row counts / width / dtype (control plane, a few hundred bytes);
+    (2) ONE message per rank with its rows concatenated, posted as a group: ``dst`` posts world-1 receives into
+    exact-size buffers, every other rank one send.  On RCCL the group is a single ncclGroupStart/End, i.e. 7
+    concurrent transfers over 7 different xGMI links at 8 GPUs; nothing is padded and nothing is broadcast."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return [list(local)]
-    if dist.get_backend() == "gloo":          # gloo moves host memory: stage device tensors through the CPU
+    gloo = dist.get_backend() == "gloo"
+    if gloo:                                    # gloo moves host memory: stage device tensors through the CPU
         local = [t.cpu() for t in local]
     ref = local[0] if len(local) else None
-    device = ref.device if ref is not None else torch.device("cuda" if dist.get_backend() == "nccl" else "cpu")
-    # 1. counts: (max_clips_per_rank,) per rank, -1 padded
+    device = ref.device if ref is not None else torch.device("cpu" if gloo else "cuda")
+    # 1. metadata: [n_clips, width, dtype code, rows of clip 0, rows of clip 1, ...] padded to the largest clip count
     n_local = torch.tensor([len(local)], dtype=torch.int64, device=device)
     all_n = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(all_n, n_local)
     max_clips = max(int(t.item()) for t in all_n)
-    meta = torch.full((max_clips + 1,), -1, dtype=torch.int64, device=device)
+    meta = torch.full((max_clips + 2,), -1, dtype=torch.int64, device=device)
     for i, t in enumerate(local):
         meta[i] = t.shape[0]
-    meta[max_clips] = local[0].shape[1] if len(local) else -1
+    if len(local):
+        meta[max_clips] = local[0].shape[1]
+        meta[max_clips + 1] = _DT.index(local[0].dtype)
     all_meta = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(all_meta, meta)
+    all_meta = [m.cpu() for m in all_meta]
     width = max(int(m[max_clips].item()) for m in all_meta)
-    totals = [int(m[:max_clips].clamp(min=0).sum().item()) for m in all_meta]
-    max_rows = max(totals)
-    dtype = None
-    for t in local:
-        dtype = t.dtype
-    dt_code = torch.tensor([_DT.index(dtype) if dtype is not None else -1], dtype=torch.int64, device=device)
-    all_dt = [torch.zeros_like(dt_code) for _ in range(world)]
-    dist.all_gather(all_dt, dt_code)
-    dtype = _DT[max(int(t.item()) for t in all_dt)]
-    # 2. padded gather of the concatenated rows
-    buf = torch.zeros((max_rows, width), dtype=dtype, device=device)
-    if len(local):
-        cat = torch.cat(list(local), dim=0)
-        buf[:cat.shape[0]] = cat
-    # all_gather rather than gather: the most widely supported collective on every backend (RCCL
-    # gather is emulated with send/recv anyway); the payload is a few tens of MB per clip
-    recv = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(recv, buf)
+    dt_code = max(int(m[max_clips + 1].item()) for m in all_meta)
+    if width < 0:                               # no rank has any clip
+        return [[] for _ in range(world)] if rank == dst else None
+    dtype = _DT[dt_code]
+    counts = [[int(c) for c in m[:max_clips].tolist() if c >= 0] for m in all_meta]
+    totals = [sum(c) for c in counts]
+    # 2. one grouped point-to-point exchange
     if rank != dst:
+        if totals[rank] > 0:
+            payload = torch.cat(list(local), dim=0).contiguous()
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload, dst)]):
+                req.wait()
         return None
+    bufs = {r: torch.empty((totals[r], width), dtype=dtype, device=device) for r in range(world) if r != dst and totals[r] > 0}
+    if bufs:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, r) for r, b in bufs.items()]):
+            req.wait()
     out: List[List[torch.Tensor]] = []
     for r in range(world):
-        counts = [int(c) for c in all_meta[r][:max_clips].tolist() if c >= 0]
+        if r == dst:
+            out.append(list(local))
+            continue
         rows, off = [], 0
-        for c in counts:
-            rows.append(recv[r][off:off + c])
+        for c in counts[r]:
+            rows.append(bufs[r][off:off + c] if c else torch.empty((0, width), dtype=dtype, device=device))
             off += c
         out.append(rows)
     return out
+
+
+def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optional[str] = None,
+                 behaviors: Optional[Sequence[str]] = None, temperature: float = 1.0,
+                 progress_callback=None) -> Optional[List[dict]]:
+    """Drain a list of videos on all ranks: what the reference's EncodeThread queue (+ ClassificationThread when a model
+    is live) does on one device (backend/workthreads.py:276-348, 453-519), sharded by clip.
+
+    Clip i belongs to rank i mod world (``shard_clips``).  The ranks walk the list in rounds of ``world`` clips: every
+    rank encodes its clip of the round with ``encode_file``'s chunk loop (and classifies it with ``infer_file``'s
+    window loop when ``head`` is given), then the rows are gathered to rank 0 (``gather_rows``), which writes
+    ``<video>_cls.h5`` (and ``<video>_<dataset_name>_outputs.csv``) in clip order with the reference's file semantics
+    (``.tmp`` + rename, encoder stamp, CSV header = behaviours).  A clip that fails on its rank is logged there and
+    skipped, as EncodeThread does (workthreads.py:334-336); a video without frames yields no file.
+
+    Returns on rank 0 one record per clip {"path", "frames", "cls_file", "csv_file", "status"}, status in
+    {"ok", "empty", "failed"}; ``None`` on the other ranks.  Every rank must call it with the same ``paths``."""
+    import numpy as np
+    from . import pipeline as P
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    gloo = dist.is_initialized() and dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if (gloo or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
+    paths = list(paths)
+    if head is not None and (dataset_name is None or behaviors is None):
+        raise ValueError("classification needs dataset_name and behaviors (infer_file's arguments)")
+    D = encoder.config.hidden_size
+    results: List[dict] = []
+    for base in range(0, len(paths), world):
+        mine = base + rank
+        rows = probs = None
+        status = 3                                              # 0 ok, 1 empty video, 2 failed, 3 no clip this round
+        if mine < len(paths):
+            try:
+                rows = P.encode_rows(encoder, paths[mine], progress_callback)
+                if rows is None:
+                    status = 1
+                else:
+                    if head is not None and rows.shape[0] > 0:
+                        hdev = encoder.device if hasattr(encoder, "device") else dev
+                        probs = head.infer_clip(torch.from_numpy(rows).to(hdev), float(temperature)).cpu().numpy()
+                    status = 0
+            except Exception as e:  # noqa: BLE001 - the queue survives a bad file (workthreads.py:334-336)
+                print(f"ERROR during encoding for {paths[mine]} on rank {rank}: {e}")
+                rows = probs = None
+                status = 2
+        # round status of every rank (control plane), then the two row gathers
+        st = torch.tensor([status], dtype=torch.int64, device=dev)
+        if world > 1:
+            all_st = [torch.zeros_like(st) for _ in range(world)]
+            dist.all_gather(all_st, st)
+            all_st = [int(t.item()) for t in all_st]
+        else:
+            all_st = [status]
+        ok = status == 0
+        g_rows = gather_rows([torch.from_numpy(rows).to(dev)] if ok else [], dst=0)
+        g_probs = gather_rows([torch.from_numpy(probs).to(dev)] if ok and probs is not None else [], dst=0) if head is not None else None
+        if rank != 0:
+            continue
+        for r in range(world):
+            clip = base + r
+            if clip >= len(paths):
+                break
+            rec = {"path": paths[clip], "frames": 0, "cls_file": None, "csv_file": None,
+                   "status": {0: "ok", 1: "empty", 2: "failed"}[all_st[r]]}
+            if all_st[r] == 0:
+                try:
+                    r16 = g_rows[r][0].cpu().numpy()
+                    rec["frames"] = int(r16.shape[0])
+                    rec["cls_file"] = P.write_cls_file(paths[clip], r16)
+                    print(f"Successfully encoded {os.path.basename(paths[clip])} to {os.path.basename(rec['cls_file'])}")
+                    if head is not None and g_probs[r]:
+                        csv = rec["cls_file"].replace("_cls.h5", f"_{dataset_name}_outputs.csv")
+                        P.write_probs_csv(csv, g_probs[r][0].cpu().numpy(), list(behaviors))
+                        rec["csv_file"] = csv
+                except Exception as e:  # noqa: BLE001
+                    print(f"ERROR writing outputs of {paths[clip]}: {e}")
+                    rec["status"] = "failed"
+            results.append(rec)
+    return results if rank == 0 else None
 
 
 _DT = [torch.float16, torch.float32, torch.uint8, torch.int64, torch.bfloat16]

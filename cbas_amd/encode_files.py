@@ -1,0 +1,94 @@
+"""Encode (and optionally classify) a list of videos on every GPU of the node, one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m cbas_amd.encode_files \
+        --encoder <checkpoint dir | HF id in the local cache> [--model-bundle <dir with model.pth + model_meta.json>] \
+        [--dataset-name NAME] video1.mp4 video2.mp4 ...        (or --dir <recordings root>)
+
+What the reference does with its EncodeThread queue and, when a model is live, its ClassificationThread queue
+(backend/workthreads.py:276-348, 453-519) on one device: here clip i goes to rank i mod N, and rank 0 writes
+``<video>_cls.h5`` / ``<video>_<dataset>_outputs.csv`` exactly as ``encode_file`` / ``infer_file`` do.  Works unchanged
+with one process (no torchrun).  With ``--dir`` the videos are those the reference would queue on project load
+(startup_page.py:80-126): every ``*.mp4`` without an up-to-date ``_cls.h5``.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from typing import List
+
+import torch
+
+
+def _needs_encoding(video: str, stamp: str) -> bool:
+    """startup_page.py:92-117: missing, unreadable, unstamped or differently stamped `_cls.h5` -> (re)encode."""
+    from . import h5io
+    h5 = os.path.splitext(video)[0] + "_cls.h5"
+    if not os.path.exists(h5):
+        return True
+    try:
+        with h5io.ClsReader(h5) as r:
+            return r.attrs.get("encoder_model_identifier") != stamp
+    except Exception:  # noqa: BLE001
+        return True
+
+
+def find_videos(root: str, stamp: str) -> List[str]:
+    out = []
+    for d, _sub, files in os.walk(root):
+        for f in sorted(files):
+            if f.lower().endswith(".mp4") and _needs_encoding(os.path.join(d, f), stamp):
+                out.append(os.path.join(d, f))
+    return sorted(out)
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("videos", nargs="*")
+    ap.add_argument("--dir", default=None, help="recordings root: encode every .mp4 lacking an up-to-date _cls.h5")
+    ap.add_argument("--encoder", required=True, help="encoder_model_identifier: checkpoint directory or cached HF id")
+    ap.add_argument("--model-bundle", default=None, help="directory with model.pth + config.yaml + model_meta.json")
+    ap.add_argument("--dataset-name", default=None, help="<video>_<dataset-name>_outputs.csv (default: the bundle's name)")
+    ap.add_argument("--max-batch", type=int, default=64)
+    ap.add_argument("--max-frame", type=int, nargs=2, default=(256, 256))
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2))
+    args = ap.parse_args(argv)
+
+    from . import dist as cdist, pipeline as P
+    from .bundle import load_model_bundle
+    from .encoder import DinoEncoder
+    rank, world, local = cdist.init_from_env()
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    videos = list(args.videos)
+    if args.dir:
+        videos += find_videos(args.dir, args.encoder)
+    if not videos:
+        if rank == 0:
+            print("nothing to encode")
+        return 0
+    P.set_project_stamp(args.encoder)                       # what gui_state.proj.encoder_model_identifier is to encode_file
+    enc = DinoEncoder(args.encoder, device=device, max_batch=args.max_batch, max_frame=tuple(args.max_frame),
+                      precision=args.precision)
+    head = meta = None
+    if args.model_bundle:
+        head, meta = load_model_bundle(args.model_bundle, device=device, project_encoder=args.encoder,
+                                       in_features=enc.config.hidden_size)
+        if head is None:
+            return 2
+    hp = (meta or {}).get("hyperparameters", {})
+    name = args.dataset_name or os.path.basename(os.path.normpath(args.model_bundle or "")) or None
+    temperature = float((meta or {}).get("calibration", {}).get("temperature", 1.0))        # workthreads.py:484
+    recs = cdist.encode_files(videos, enc, head=head, dataset_name=name, behaviors=hp.get("behaviors"),
+                              temperature=temperature)
+    cdist.barrier()
+    if rank == 0:
+        ok = sum(r["status"] == "ok" for r in recs)
+        print(f"{ok} of {len(recs)} videos encoded on {world} GPU(s); {sum(r['frames'] for r in recs)} frames")
+    enc.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -112,6 +112,8 @@ class Y4MFileSource:
 class PipeFrameSource:
     """Sequential frames from an external decoder writing Y4M to its stdout."""
 
+    decodes_ahead = True           # its reader thread already runs ahead of the consumer (pipeline._chunks)
+
     DECODE_CMD: Sequence[str] = ("ffmpeg", "-v", "error", "-i", "{path}", "-vf", "extractplanes=g", "-pix_fmt", "gray",
                                  "-f", "yuv4mpegpipe", "-")
     PROBE_CMD: Sequence[str] = ("ffprobe", "-v", "error", "-select_streams", "v:0", "-count_packets", "-show_entries",

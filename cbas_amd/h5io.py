@@ -78,6 +78,7 @@ class _HDF5:
         self.Sget_simple_extent_dims = sig("H5Sget_simple_extent_dims", C.c_int, hid_t, P(hsize_t), P(hsize_t))
         self.Pcreate = sig("H5Pcreate", hid_t, hid_t)
         self.Pset_chunk = sig("H5Pset_chunk", herr_t, hid_t, C.c_int, P(hsize_t))
+        self.Pset_obj_track_times = sig("H5Pset_obj_track_times", herr_t, hid_t, C.c_uint)
         self.Pclose = sig("H5Pclose", herr_t, hid_t)
         self.Dcreate2 = sig("H5Dcreate2", hid_t, hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t)
         self.Dopen2 = sig("H5Dopen2", hid_t, hid_t, C.c_char_p, hid_t)
@@ -160,6 +161,9 @@ class ClsWriter:
         sp = H.Screate_simple(2, _dims(0, dim), _dims(_H5S_UNLIMITED, dim))
         pl = H.Pcreate(H.P_DATASET_CREATE)
         H.Pset_chunk(pl, 2, _dims(CHUNK_ROWS, dim))
+        # h5py creates datasets with track_times=False (what the reference's files look like): no creation / modification
+        # timestamps in the object header, so equal rows give byte-identical files
+        H.Pset_obj_track_times(pl, 0)
         self._did = H.Dcreate2(self._fid, b"cls", H.T_F16, sp, 0, pl, 0)
         H.Pclose(pl); H.Sclose(sp)
         if self._did < 0:

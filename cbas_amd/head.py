@@ -27,9 +27,10 @@ _ORDER_PREFIX = ["gate", "attention_temp"]
 def pack_head_weights(cfg: HeadConfig, w: Mapping[str, np.ndarray]) -> np.ndarray:
     """Flatten a ClassifierLSTMDeltas state dict into the blob order of include/cbas_mi355x.h."""
     names = list(_ORDER_PREFIX)
-    for s in ("cls", "delta", "acc"):
+    streams = ("cls", "delta", "acc") if cfg.use_acceleration else ("cls", "delta")
+    for s in streams:
         names += [f"{s}_bottleneck.0.weight", f"{s}_bottleneck.0.bias"]
-    for s in ("cls", "delta", "acc"):
+    for s in streams:
         names += [f"{s}_ln.weight", f"{s}_ln.bias"]
     names += ["lin0.0.weight", "lin0.0.bias", "lin1.weight", "lin1.bias"]
     for layer in range(cfg.lstm_layers):
@@ -72,8 +73,28 @@ class ClassifierLSTMDeltas:
         self._lib = None
 
     # -- nn.Module-like surface ------------------------------------------------------------------
+    # initial values of the two scalar parameters (classifier_head.py:90, 96): what a non-strict load keeps when the
+    # checkpoint lacks them
+    _SCALAR_DEFAULTS = {"gate": 0.2, "attention_temp": 1.0}
+
     def load_state_dict(self, state_dict, strict: bool = True):
-        self._weights = {k: _to_numpy(v) for k, v in state_dict.items()}
+        """``strict=False`` (how the reference's bundle loader calls it, workthreads.py:441): entries this architecture
+        does not have are ignored and the scalar parameters may be missing.  A missing TENSOR is an error in both
+        modes: torch would silently keep its random initialisation for it."""
+        from .weights import head_param_shapes
+        shapes = head_param_shapes(self.config)
+        w = {k: _to_numpy(v) for k, v in state_dict.items()}
+        extra = [k for k in w if k not in shapes]
+        missing = [k for k in shapes if k not in w]
+        if strict and (extra or missing):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {extra}")
+        for k in list(missing):
+            if k in self._SCALAR_DEFAULTS:
+                w[k] = np.asarray(self._SCALAR_DEFAULTS[k], np.float32)
+                missing.remove(k)
+        if missing:
+            raise RuntimeError(f"state_dict lacks {missing}: the MI355X head will not run on uninitialised weights")
+        self._weights = {k: w[k] for k in shapes}
         self._destroy()
         return self
 
@@ -121,7 +142,8 @@ class ClassifierLSTMDeltas:
         cfg = self.config
         self._lib = _lib.load()
         cc = _lib.HeadConfigC(cfg.in_features, cfg.out_features, cfg.seq_len, cfg.bottleneck_dim, cfg.lin0_dim,
-                              cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers)
+                              cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers,
+                              int(cfg.use_acceleration))
         blob = pack_head_weights(cfg, self._weights)
         need = self._lib.cbas_head_weights_count(C.byref(cc))
         if need != blob.shape[0]:
@@ -181,6 +203,7 @@ def from_reference_module(module, device) -> ClassifierLSTMDeltas:
     h = int(sd["attention_head.weight"].shape[1]) // 2
     m = ClassifierLSTMDeltas(module.in_features, module.out_features, seq_len=module.seq_len,
                              center_window_size=module.sw, ema_alpha=module.ema_alpha, lstm_hidden_size=h,
-                             lstm_layers=int(getattr(module.lstm, "num_layers", 1)))
+                             lstm_layers=int(getattr(module.lstm, "num_layers", 1)),
+                             use_acceleration=bool(getattr(module, "use_acceleration", "acc_bottleneck.0.weight" in sd)))
     m.load_state_dict(sd)
     return m.to(device)

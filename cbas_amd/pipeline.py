@@ -222,6 +222,140 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
         raise e
 
 
+class _MemWriter:
+    """``ClsWriter``-shaped sink that keeps the rows in memory (the multi-GPU driver ships them to the writing rank)."""
+
+    def __init__(self):
+        self.parts: List[np.ndarray] = []
+
+    def append(self, rows):
+        self.parts.append(np.array(rows, copy=True))
+
+    def flush(self):
+        pass
+
+
+def encode_rows(encoder: DinoEncoder, path: str, progress_callback=None, reader=None) -> Optional[np.ndarray]:
+    """The chunk loop of ``encode_file`` without the file: (N, D) float16 CLS rows of one video, ``None`` for a video
+    without frames.  Reader and encoder errors propagate, with the encoder left reusable."""
+    own_reader = reader is None
+    reader = reader if reader is not None else open_video(path)
+    try:
+        video_len = len(reader)
+        if video_len == 0:
+            print(f"Warning: Video {path} contains no frames. Skipping.")
+            return None
+        w = _MemWriter()
+        try:
+            _stream_chunks(encoder, reader, video_len, progress_callback, w, _lib.ENC_SLOTS)
+        except Exception:
+            for slot in range(_lib.ENC_SLOTS):
+                if slot in getattr(encoder, "_slot_n", {}):
+                    try:
+                        encoder.wait(slot)
+                    except Exception:  # noqa: BLE001
+                        pass
+            raise
+        D = encoder.config.hidden_size
+        return np.concatenate(w.parts) if w.parts else np.empty((0, D), np.float16)
+    finally:
+        if own_reader and hasattr(reader, "close"):
+            reader.close()
+
+
+def write_cls_file(video_path: str, rows: np.ndarray) -> str:
+    """Write ``<video>_cls.h5`` for already-encoded rows with encode_file's file semantics (backend/cbas.py:410-421,
+    442): ``.tmp`` first, stamp attributes when a project is set, atomic rename; the ``.tmp`` is removed on failure."""
+    out_file_path = os.path.splitext(video_path)[0] + "_cls.h5"
+    tmp_file_path = out_file_path + ".tmp"
+    attrs = {}
+    stamp = _current_stamp()
+    if stamp:
+        attrs = {"encoder_model_identifier": stamp, "schema_version": SCHEMA_VERSION}
+    try:
+        with h5io.ClsWriter(tmp_file_path, rows.shape[1], attrs) as w:
+            for i in range(0, rows.shape[0], CHUNK_SIZE):            # same append granularity as the chunk loop
+                w.append(rows[i:i + CHUNK_SIZE])
+                w.flush()
+        os.replace(tmp_file_path, out_file_path)
+    except Exception:
+        if os.path.exists(tmp_file_path):
+            try:
+                os.remove(tmp_file_path)
+            except OSError:
+                pass
+        raise
+    return out_file_path
+
+
+class _ChunkPrefetcher:
+    """Decode ahead: ``reader.get_batch`` for chunk k+1 (and k+2) runs on a background thread while chunk k is being
+    staged and encoded.  The reference decodes, converts, copies and computes strictly in turn (cbas.py:425-438); with
+    the ViT ~100x faster the decoder (decord's libav call releases the GIL) is what has to be kept busy.  Works with any
+    reader that has ``get_batch``; chunks are delivered in order, a decoder error is re-raised at the chunk it
+    belongs to.  Readers that already decode ahead on their own thread (``PipeFrameSource``) are used directly."""
+
+    def __init__(self, reader, video_len: int, depth: int = 2):
+        import queue
+        import threading
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._stop = threading.Event()
+        self._reader, self._n = reader, video_len
+        self._t = threading.Thread(target=self._run, name="cbas-decode-ahead", daemon=True)
+        self._t.start()
+
+    def _put(self, item) -> bool:
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self):
+        for i in range(0, self._n, CHUNK_SIZE):
+            end = min(i + CHUNK_SIZE, self._n)
+            try:
+                item = (i, end, self._reader.get_batch(range(i, end)))
+            except BaseException as e:  # noqa: BLE001 - delivered to the consumer in order
+                self._put((i, end, e))
+                return
+            if not self._put(item):
+                return
+
+    def __iter__(self):
+        for _ in range(0, self._n, CHUNK_SIZE):
+            i, end, frames = self._q.get()
+            if isinstance(frames, BaseException):
+                raise frames
+            yield i, end, frames
+
+    def close(self):
+        self._stop.set()
+        while True:                                  # unblock a producer waiting on a full queue
+            try:
+                self._q.get_nowait()
+            except Exception:  # noqa: BLE001
+                break
+        self._t.join(timeout=5)
+
+
+def _chunks(reader, video_len: int):
+    """(start, end, frames) per 512-frame chunk, decoded ahead unless the reader does that itself."""
+    if getattr(reader, "decodes_ahead", False) or os.environ.get("CBAS_DECODE_AHEAD") == "0":
+        for i in range(0, video_len, CHUNK_SIZE):
+            end = min(i + CHUNK_SIZE, video_len)
+            yield i, end, reader.get_batch(range(i, end))
+        return
+    pf = _ChunkPrefetcher(reader, video_len)
+    try:
+        yield from pf
+    finally:
+        pf.close()
+
+
 def _stream_chunks(encoder: DinoEncoder, reader, video_len: int, progress_callback, w, nslots: int) -> None:
     """The chunk loop of encode_file (cbas.py:423-440) on the asynchronous slots."""
     inflight: deque = deque()        # (slot, n_frames) in submission order
@@ -234,9 +368,7 @@ def _stream_chunks(encoder: DinoEncoder, reader, video_len: int, progress_callba
         w.append(rows)
         free.append(slot)
 
-    for i in range(0, video_len, CHUNK_SIZE):
-        end_index = min(i + CHUNK_SIZE, video_len)
-        frames_np = reader.get_batch(range(i, end_index))     # (n,H,W,3) uint8, host
+    for i, end_index, frames_np in _chunks(reader, video_len):     # (n,H,W,3) uint8, host; decoded ahead
         if progress_callback:
             progress_callback((end_index / video_len) * 100)
         frames_np = np.ascontiguousarray(frames_np)

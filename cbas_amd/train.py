@@ -61,6 +61,9 @@ class HeadTrainer:
                  weight_decay: float = 0.0, label_smoothing: float = 0.0, class_weights: Optional[Sequence[float]] = None,
                  max_batch: int = 512, seed: int = 0, dropout: bool = True):
         cfg.validate()
+        if not cfg.use_acceleration or cfg.lstm_hidden_size not in (64, 128):
+            raise NotImplementedError("on-device training is built for the 3-stream head with lstm_hidden_size 64 or 128 "
+                                      "(the configurations train_lstm_model / sweep_runner.py use); inference supports more")
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -68,7 +71,7 @@ class HeadTrainer:
         self._lib = _lib.load()
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._cc = _lib.HeadConfigC(cfg.in_features, cfg.out_features, cfg.seq_len, cfg.bottleneck_dim, cfg.lin0_dim,
-                                    cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers)
+                                    cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers, 1)
         tc = _lib.TrainConfigC(float(lr), float(weight_decay), float(label_smoothing), int(max_batch), int(seed) & (2 ** 64 - 1),
                                1 if dropout else 0)
         blob = pack_head_weights(cfg, weights)

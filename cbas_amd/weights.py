@@ -187,12 +187,13 @@ def synth_encoder_weights(cfg: ViTConfig, seed: int = 1234) -> Dict[str, np.ndar
 def head_param_shapes(cfg: HeadConfig) -> Dict[str, Tuple[int, ...]]:
     I, C, Bn, h, L0 = cfg.in_features, cfg.out_features, cfg.bottleneck_dim, cfg.lstm_hidden_size, cfg.lin0_dim
     s: Dict[str, Tuple[int, ...]] = {"gate": (), "attention_temp": ()}
-    for stream in ("cls", "delta", "acc"):
+    streams = ("cls", "delta", "acc") if cfg.use_acceleration else ("cls", "delta")     # classifier_head.py:74-84
+    for stream in streams:
         s[f"{stream}_bottleneck.0.weight"] = (Bn, I)
         s[f"{stream}_bottleneck.0.bias"] = (Bn,)
         s[f"{stream}_ln.weight"] = (Bn,)
         s[f"{stream}_ln.bias"] = (Bn,)
-    s["lin0.0.weight"] = (L0, 3 * Bn)
+    s["lin0.0.weight"] = (L0, len(streams) * Bn)
     s["lin0.0.bias"] = (L0,)
     s["attention_head.weight"] = (1, 2 * h)
     s["attention_head.bias"] = (1,)

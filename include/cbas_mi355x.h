@@ -198,17 +198,19 @@ typedef struct cbas_head_config {
     int32_t seq_len;            /* 31                         */
     int32_t bottleneck_dim;     /* 128                        */
     int32_t lin0_dim;           /* 256                        */
-    int32_t lstm_hidden_size;   /* 64 (or 128)                */
+    int32_t lstm_hidden_size;   /* 64; any multiple of 16 up to 128 (inferred from the weights: workthreads.py:418-421) */
     int32_t center_window_size; /* 5                          */
     float   ema_alpha;          /* 0.3                        */
     int32_t lstm_layers;        /* 1 (stacked BiLSTM layers)  */
+    int32_t use_acceleration;   /* 1: cls + delta + acc bottleneck streams; 0: cls + delta only
+                                   (classifier_head.py:74-84, 158-162): the acc_* entries are then absent from the blob */
 } cbas_head_config;
 
 /* float32 elements expected by cbas_head_create, in this order (state_dict names):
  *   gate[1] attention_temp[1]
  *   cls_bottleneck.0.weight[Bn*I] .bias[Bn]  delta_bottleneck.0.weight .bias  acc_bottleneck.0.weight .bias
- *   cls_ln.weight[Bn] .bias[Bn]  delta_ln.weight .bias  acc_ln.weight .bias
- *   lin0.0.weight[L0*3Bn] .bias[L0]
+ *   cls_ln.weight[Bn] .bias[Bn]  delta_ln.weight .bias  acc_ln.weight .bias        (acc_* only when use_acceleration)
+ *   lin0.0.weight[L0*NS*Bn] .bias[L0]                                                (NS = 3 or 2 streams)
  *   lin1.weight[C*I] .bias[C]
  *   per LSTM layer k = 0..lstm_layers-1 (input width L0 for k = 0, 2h above):
  *     lstm.weight_ih_lk[4h*in] weight_hh_lk[4h*h] bias_ih_lk[4h] bias_hh_lk[4h], then the same four _reverse

@@ -85,7 +85,9 @@ def head_forward(x: np.ndarray, w: Dict[str, np.ndarray], seq_len: int = 31, sw:
         y = gelu_erf(stream @ w[f"{name}_bottleneck.0.weight"].T + w[f"{name}_bottleneck.0.bias"])
         return layer_norm(y, w[f"{name}_ln.weight"], w[f"{name}_ln.bias"], 1e-5)
 
-    aug = np.concatenate([bott(s, "cls"), bott(d, "delta"), bott(a, "acc")], axis=-1)
+    # use_acceleration=False (:74-84, :158-162): no acc_* parameters, two streams
+    streams = [bott(s, "cls"), bott(d, "delta")] + ([bott(a, "acc")] if "acc_bottleneck.0.weight" in w else [])
+    aug = np.concatenate(streams, axis=-1)
 
     # lin0 + centring, :164-167
     xl = gelu_erf(aug @ w["lin0.0.weight"].T + w["lin0.0.bias"])

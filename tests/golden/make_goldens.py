@@ -243,6 +243,7 @@ def g_vitl518(out):
 def ref_head(classifier_head, hcfg: C.HeadConfig, hw):
     m = classifier_head.ClassifierLSTMDeltas(
         in_features=hcfg.in_features, out_features=hcfg.out_features, seq_len=hcfg.seq_len,
+        use_acceleration=hcfg.use_acceleration,
         lstm_hidden_size=hcfg.lstm_hidden_size, lstm_layers=hcfg.lstm_layers).eval()
     res = m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in hw.items()}, strict=True)
     return m
@@ -261,6 +262,45 @@ def g_head(out):
         np.savez_compressed(os.path.join(out, f"head_{tag}.npz"), logits=logits.numpy(), latent=latent.numpy(),
                             x_sha=sha(x), walk_seed=21)
         print("head", tag, logits.shape, latent.shape)
+
+
+def g_head_variants(out):
+    """Round 2: the constructor arguments round 1 left out - the sweep's sequence lengths (sweep_runner.py:110 lists
+    [31, 63, 95]), hidden sizes other than 64 / 128 (the loader infers any size: workthreads.py:418-421) and
+    use_acceleration=False (classifier_head.py:74-84,158-162) - forward goldens, plus infer_file at seq_len 63 / 95."""
+    cbas, classifier_head = import_reference()
+    for tag, kw in (("h64_t63", dict(seq_len=63)), ("h64_t95", dict(seq_len=95)), ("h32", dict(lstm_hidden_size=32)),
+                    ("h96_t63", dict(lstm_hidden_size=96, seq_len=63)), ("h64_noacc", dict(use_acceleration=False)),
+                    ("h48_noacc_l2_t15", dict(use_acceleration=False, lstm_hidden_size=48, lstm_layers=2, seq_len=15))):
+        hcfg = C.HeadConfig(in_features=768, out_features=9, **kw)
+        hw = W.synth_head_weights(hcfg, HEAD_SEED)
+        m = ref_head(classifier_head, hcfg, hw)
+        T = hcfg.seq_len
+        seq = synth.cls_walk(21, 48 + T - 1, 768).astype(np.float32)
+        x = np.stack([seq[i:i + T] for i in range(48)])
+        logits, latent = m(torch.from_numpy(x))
+        np.savez_compressed(os.path.join(out, f"head_{tag}.npz"), logits=logits.detach().numpy(), latent=latent.detach().numpy(),
+                            x_sha=sha(x), walk_seed=21)
+        print("head variant", tag, logits.shape, latent.shape)
+    os.replace = _real_replace
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for n, T, temp in ((40, 63, 1.0), (300, 63, 0.9), (260, 95, 1.0)):        # n < seq_len and n > seq_len
+            hcfg = C.HeadConfig(seq_len=T)
+            m = ref_head(classifier_head, hcfg, W.synth_head_weights(hcfg, HEAD_SEED))
+            p = os.path.join(td, f"clip{n}_{T}_cls.h5")
+            cls = synth.cls_walk(500 + n + T, n, 768)
+            with _FakeH5File(p, "w") as f:
+                d = f.create_dataset("cls", shape=(n, 768), dtype="f2")
+                d[:] = cls
+            o = cbas.infer_file(p, m, "gold", BEHAVIORS, T, device=torch.device("cpu"), temperature=temp)
+            assert o is not None
+            import pandas as pd
+            res[f"probs_{n}_{T}"] = pd.read_csv(o).to_numpy(dtype=np.float64).astype(np.float32)
+            res[f"temp_{n}_{T}"] = np.float64(temp)
+            res[f"cls_sha_{n}_{T}"] = sha(cls)
+            print("infer variant", n, T)
+    np.savez_compressed(os.path.join(out, "infer_file_seq.npz"), **res)
 
 
 class _MaskDropout(torch.nn.Module):
@@ -488,7 +528,7 @@ def g_dinov2(out):
 
 
 ALL = {"dinov2": g_dinov2, "tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
-       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e,
+       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_variants": g_head_variants, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e,
        "encode_file": g_encode_file}
 
 if __name__ == "__main__":

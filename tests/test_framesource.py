@@ -93,3 +93,45 @@ def test_encode_file_from_y4m_and_pipe_equals_npy(tmp_path):
     got2 = rows(P.encode_file(enc, y4m2, reader=_pipe_source(y4m2, 90, prefetch_frames=32)))
     enc.close()
     assert ref.shape == (90, cfg.hidden_size) and np.array_equal(ref, got) and np.array_equal(ref, got2)
+
+
+def test_decode_ahead_overlaps_and_preserves_order_and_errors():
+    """pipeline._chunks: any reader's get_batch runs ahead on a thread (what keeps decord busy while the GPU works),
+    chunks arrive in order with the right contents, and a decoder error surfaces at its chunk."""
+    import threading
+    import time
+    import numpy as np
+    from cbas_amd import pipeline as P
+
+    class SlowReader:
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at, self.calls, self.threads = n, fail_at, [], set()
+
+        def __len__(self):
+            return self.n
+
+        def get_batch(self, idx):
+            idx = list(idx)
+            self.calls.append((idx[0], time.perf_counter()))
+            self.threads.add(threading.current_thread().name)
+            time.sleep(0.05)
+            if self.fail_at is not None and idx[0] >= self.fail_at:
+                raise IOError(f"decode failed at {idx[0]}")
+            return np.full((len(idx), 2, 2, 3), idx[0] // 512, np.uint8)
+
+    r = SlowReader(512 * 5 + 7)
+    t0 = time.perf_counter()
+    seen = []
+    for i, end, fr in P._chunks(r, len(r)):
+        time.sleep(0.05)                                   # the "GPU work" of the consumer
+        seen.append((i, end, int(fr[0, 0, 0, 0]), fr.shape[0]))
+    wall = time.perf_counter() - t0
+    assert seen == [(k * 512, min((k + 1) * 512, len(r)), k, min(512, len(r) - k * 512)) for k in range(6)]
+    assert r.threads == {"cbas-decode-ahead"}
+    assert wall < 0.05 * 12 * 0.8                          # decode and consume overlapped (serial would be 0.6 s)
+    bad = SlowReader(512 * 4, fail_at=1024)
+    got = []
+    with pytest.raises(IOError, match="1024"):
+        for i, end, fr in P._chunks(bad, len(bad)):
+            got.append(i)
+    assert got == [0, 512]

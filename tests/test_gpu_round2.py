@@ -238,3 +238,114 @@ def test_fused_session_host_and_device_pushes_equal_two_step_path():
     finally:
         head.close()
         enc.close()
+
+
+HEAD_VARIANTS = [("h64_t63", dict(seq_len=63)), ("h64_t95", dict(seq_len=95)), ("h32", dict(lstm_hidden_size=32)),
+                 ("h96_t63", dict(lstm_hidden_size=96, seq_len=63)), ("h64_noacc", dict(use_acceleration=False)),
+                 ("h48_noacc_l2_t15", dict(use_acceleration=False, lstm_hidden_size=48, lstm_layers=2, seq_len=15))]
+
+
+@pytest.mark.parametrize("tag,kw", HEAD_VARIANTS, ids=[t for t, _ in HEAD_VARIANTS])
+def test_head_variants_against_reference_goldens(golden_dir, tag, kw):
+    """The head configurations the reference constructor / loader accept beyond the defaults: seq_len 63 and 95
+    (sweep_runner.py:110), lstm_hidden_size other than 64 / 128 (workthreads.py:418-421), use_acceleration=False
+    (classifier_head.py:74-84,158-162) - logits and latent vs the reference module's outputs."""
+    import os
+    from cbas_amd.head import ClassifierLSTMDeltas
+    g = np.load(os.path.join(golden_dir, f"head_{tag}.npz"))
+    hc = C.HeadConfig(in_features=768, out_features=9, **kw)
+    m = ClassifierLSTMDeltas(768, 9, **kw)
+    m.load_state_dict(W.synth_head_weights(hc, 4321))
+    m.to("cuda")
+    T = hc.seq_len
+    seq = synth.cls_walk(21, 48 + T - 1, 768).astype(np.float32)
+    x = torch.from_numpy(np.stack([seq[i:i + T] for i in range(48)])).cuda()
+    logits, latent = m(x)
+    logits, latent = logits.cpu().numpy(), latent.cpu().numpy()
+    m.close()
+    np.testing.assert_allclose(logits, g["logits"], atol=1e-4)
+    np.testing.assert_allclose(latent, g["latent"], atol=5e-5)
+    assert (logits.argmax(1) == g["logits"].argmax(1)).all()
+
+
+@pytest.mark.parametrize("n,T", [(40, 63), (300, 63), (260, 95)])
+def test_infer_clip_long_windows(golden_dir, n, T):
+    """infer_file semantics at the sweep's longer windows, incl. a clip shorter than the window (all-replicate padding)."""
+    import os
+    from cbas_amd.head import ClassifierLSTMDeltas
+    g = np.load(os.path.join(golden_dir, "infer_file_seq.npz"))
+    m = ClassifierLSTMDeltas(768, 9, seq_len=T)
+    m.load_state_dict(W.synth_head_weights(C.HeadConfig(seq_len=T), 4321))
+    m.to("cuda")
+    cls = torch.from_numpy(synth.cls_walk(500 + n + T, n, 768)).cuda()
+    probs = m.infer_clip(cls, float(g[f"temp_{n}_{T}"])).cpu().numpy()
+    m.close()
+    ref = g[f"probs_{n}_{T}"]
+    np.testing.assert_allclose(probs, ref, atol=1e-4)
+    n_flip = int((probs.argmax(1) != ref.argmax(1)).sum())
+    print(f"\ninfer_clip n={n} seq_len={T}: |dp|max {np.abs(probs - ref).max():.2e}, label flips {n_flip}")
+    assert n_flip == 0
+
+
+def test_model_bundle_round_trip_through_the_head(tmp_path):
+    """model.pth + config.yaml + model_meta.json (workthreads.py:856-886) -> load_model_bundle (:372-451 rules) ->
+    infer_file with the bundle's calibration temperature (:484) == the oracle on the same rows."""
+    from cbas_amd import bundle as B, pipeline as P, h5io
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from oracle import pipeline_oracle as PO
+    names = [f"b{i}" for i in range(9)]
+    enc_id = "facebook/dinov3-vitb16-pretrain-lvd1689m"
+    hcfg = C.HeadConfig(lstm_hidden_size=96, seq_len=63)
+    w = W.synth_head_weights(hcfg, 17)
+    src = ClassifierLSTMDeltas(768, 9, seq_len=63, lstm_hidden_size=96)
+    src.load_state_dict(w)
+    B.save_model_bundle(str(tmp_path / "m"), src, names, "m", enc_id, temperature=1.4)
+    head, meta = B.load_model_bundle(str(tmp_path / "m"), device="cuda", project_encoder=enc_id)
+    assert head is not None and meta["hyperparameters"]["seq_len"] == 63
+    cls = synth.cls_walk(9, 400, 768)
+    path = str(tmp_path / "v_cls.h5")
+    with h5io.ClsWriter(path, 768, {}) as wr:
+        wr.append(cls)
+    T = float(meta["calibration"]["temperature"])
+    out = P.infer_file(path, head, "m", meta["hyperparameters"]["behaviors"], meta["hyperparameters"]["seq_len"],
+                       device="cuda", temperature=T)
+    assert out == str(tmp_path / "v_m_outputs.csv")
+    got = np.loadtxt(out, delimiter=",", skiprows=1, dtype=np.float32)
+    ref = PO.classify_cls(cls, w, 63, T)
+    np.testing.assert_allclose(got, ref, atol=1e-4)
+    assert (got.argmax(1) == ref.argmax(1)).all()
+    head.close()
+
+
+def test_encode_files_world1_equals_encode_file(tmp_path):
+    """The multi-GPU driver with one rank writes the same bytes as encode_file / infer_file (the world-2/3 equality
+    is checked on CPU ranks in tests/test_dist_encode_files.py)."""
+    import hashlib, os, shutil
+    from cbas_amd import dist as cdist, pipeline as P
+    from cbas_amd.head import ClassifierLSTMDeltas
+    cfg, enc = _enc("tiny", 16, (64, 64))
+    hcfg = C.HeadConfig(in_features=cfg.hidden_size, out_features=4)
+    head = ClassifierLSTMDeltas(cfg.hidden_size, 4)
+    head.load_state_dict(W.synth_head_weights(hcfg, 3))
+    head.to("cuda")
+    names = ["a", "b", "c", "d"]
+    try:
+        sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()      # noqa: E731
+        a, b = tmp_path / "a", tmp_path / "b"
+        a.mkdir(); b.mkdir()
+        for i, n in enumerate((70, 600, 31)):
+            np.save(str(a / f"v{i}.npy"), synth.cage_frames(60 + i, n, 64, 64))
+            shutil.copy(str(a / f"v{i}.npy"), str(b / f"v{i}.npy"))
+        P.set_project_stamp("enc-id")
+        exp = []
+        for i in range(3):
+            h5 = P.encode_file(enc, str(a / f"v{i}.npy"))
+            exp.append((sha(h5), sha(P.infer_file(h5, head, "ds", names, 31, device="cuda", temperature=0.7))))
+        recs = cdist.encode_files([str(b / f"v{i}.npy") for i in range(3)], enc, head=head, dataset_name="ds",
+                                  behaviors=names, temperature=0.7)
+        assert [r["status"] for r in recs] == ["ok"] * 3 and [r["frames"] for r in recs] == [70, 600, 31]
+        assert [(sha(r["cls_file"]), sha(r["csv_file"])) for r in recs] == exp
+    finally:
+        P.set_project_stamp(None)
+        head.close()
+        enc.close()

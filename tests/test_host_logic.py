@@ -87,13 +87,13 @@ def test_weight_counts_agree_between_host_and_library():
     hc2 = Cfg.HeadConfig(lstm_layers=2)
     hb2 = pack_head_weights(hc2, W.synth_head_weights(hc2, 2))
     hcc2 = _lib.HeadConfigC(hc2.in_features, hc2.out_features, hc2.seq_len, hc2.bottleneck_dim, hc2.lin0_dim,
-                            hc2.lstm_hidden_size, hc2.center_window_size, hc2.ema_alpha, 2)
+                            hc2.lstm_hidden_size, hc2.center_window_size, hc2.ema_alpha, 2, 1)
     assert lib.cbas_head_weights_count(C.byref(hcc2)) == hb2.shape[0]
-    for h in (64, 128):
-        hc = Cfg.HeadConfig(lstm_hidden_size=h, out_features=7)
+    for h, acc in ((64, True), (128, True), (48, True), (64, False)):
+        hc = Cfg.HeadConfig(lstm_hidden_size=h, out_features=7, use_acceleration=acc)
         hb = pack_head_weights(hc, W.synth_head_weights(hc, 2))
         hcc = _lib.HeadConfigC(hc.in_features, hc.out_features, hc.seq_len, hc.bottleneck_dim, hc.lin0_dim,
-                               hc.lstm_hidden_size, hc.center_window_size, hc.ema_alpha, 1)
+                               hc.lstm_hidden_size, hc.center_window_size, hc.ema_alpha, 1, int(acc))
         assert lib.cbas_head_weights_count(C.byref(hcc)) == hb.shape[0]
 
 

@@ -1,0 +1,92 @@
+"""cbas_amd.integration.install() against the REAL reference modules (imported from /root/reference with the same
+stand-ins for the absent GUI / IO packages that tests/golden/make_goldens.py uses): the unmodified worker-thread code
+must pick up the drop-ins through its `cbas.` / `classifier_head.` attribute lookups (backend/workthreads.py:47-49),
+its own model-bundle loader (`ClassificationThread._load_model`, :372-451) must build the MI355X head from a bundle
+written the way TrainingThread writes it (:856-886), and uninstall() must restore the originals.
+
+Runs in a child process (the reference modules and their stubs must not leak into this interpreter).  Needs the
+reference tree: skipped where it is absent (the GPU box)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "backend")), reason="reference tree not present")
+
+CHILD = r'''
+import json, os, sys, types
+import numpy as np, torch
+REF, REPO, TMP = sys.argv[1:4]
+for name in ("cv2", "decord", "h5py", "eel", "watchdog", "watchdog.observers", "watchdog.events"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["cv2"].VideoCapture = object
+sys.modules["decord"].VideoReader = object
+sys.modules["decord"].cpu = lambda i=0: None
+sys.modules["h5py"].File = object
+eel = sys.modules["eel"]
+eel.expose = lambda f=None, *a, **k: f
+eel.spawn = lambda *a, **k: None
+sys.modules["watchdog.observers"].Observer = object
+sys.modules["watchdog.events"].FileSystemEventHandler = object
+sys.path[:0] = [REPO, REF, os.path.join(REF, "backend")]
+
+import cbas, classifier_head, gui_state, workthreads            # the reference, unmodified
+ref_enc, ref_encode, ref_infer, ref_head = cbas.DinoEncoder, cbas.encode_file, cbas.infer_file, classifier_head.ClassifierLSTMDeltas
+
+import cbas_amd.integration as I
+from cbas_amd import bundle as B, config as C, weights as W, pipeline as P
+from cbas_amd.encoder import DinoEncoder
+from cbas_amd.head import ClassifierLSTMDeltas
+assert I.install() is True
+# the worker threads resolve these names through the modules at call time (workthreads.py:319, 495, 427, 635)
+assert workthreads.cbas.DinoEncoder is DinoEncoder and workthreads.cbas.encode_file is P.encode_file
+assert workthreads.cbas.infer_file is P.infer_file and workthreads.classifier_head.ClassifierLSTMDeltas is ClassifierLSTMDeltas
+assert workthreads.cbas.train_lstm_model.__module__ == "cbas_amd.train"
+
+# a bundle as TrainingThread writes it, loaded by the reference's own ClassificationThread._load_model
+ENC = "facebook/dinov3-vitb16-pretrain-lvd1689m"
+names = ["a", "b", "c", "d", "e"]
+hcfg = C.HeadConfig(out_features=5, lstm_hidden_size=96, seq_len=63)
+src = ClassifierLSTMDeltas(768, 5, seq_len=63, lstm_hidden_size=96)
+src.load_state_dict(W.synth_head_weights(hcfg, 11))
+mdir = os.path.join(TMP, "models", "m1")
+B.save_model_bundle(mdir, src, names, "m1", ENC, temperature=1.25)
+meta = json.load(open(os.path.join(mdir, "model_meta.json")))
+del meta["hyperparameters"]["lstm_hidden_size"], meta["hyperparameters"]["lstm_layers"]     # force the inference branch (:415-425)
+json.dump(meta, open(os.path.join(mdir, "model_meta.json"), "w"))
+
+class _Model:                      # what gui_state.proj.models holds (cbas.Model: .path, .config)
+    path, config = mdir, {"behaviors": names, "seq_len": 63}
+gui_state.proj = types.SimpleNamespace(models={"m1": _Model()}, encoder_model_identifier=ENC)
+th = workthreads.ClassificationThread("cpu")
+model, got_meta = th._load_model("m1")
+assert isinstance(model, ClassifierLSTMDeltas), type(model)
+assert model.config.lstm_hidden_size == 96 and model.seq_len == 63 and model.out_features == 5
+assert got_meta["calibration"]["temperature"] == 1.25 and gui_state.live_inference_model_object is model
+for k, v in src.state_dict().items():
+    assert torch.equal(v, model.state_dict()[k]), k
+# encoder mismatch is still refused by the reference's loader with the drop-in in place
+gui_state.proj.encoder_model_identifier = "facebook/dinov2-with-registers-base"
+assert th._load_model("m1") == (None, None)
+
+# and the reference's own torch module accepts the weights file we wrote (strict)
+I.uninstall()
+assert cbas.DinoEncoder is ref_enc and cbas.encode_file is ref_encode and cbas.infer_file is ref_infer
+assert classifier_head.ClassifierLSTMDeltas is ref_head
+m = ref_head(768, 5, seq_len=63, lstm_hidden_size=96)
+m.load_state_dict(torch.load(os.path.join(mdir, "model.pth"), weights_only=True), strict=True)
+print("INSTALL-OK")
+'''
+
+
+def test_install_patches_the_reference_and_its_loader_builds_our_head(tmp_path):
+    script = tmp_path / "child.py"
+    script.write_text(textwrap.dedent(CHILD))
+    r = subprocess.run([sys.executable, str(script), REF, REPO, str(tmp_path)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "INSTALL-OK" in r.stdout, r.stdout[-3000:]

@@ -156,3 +156,35 @@ def test_torch_restatement_against_reference_goldens(golden_dir, name, cfgname, 
     cls = VT.encode_frames(fr, w, cfg, batch=4)
     rel = np.linalg.norm(cls - g["cls"], axis=1) / np.linalg.norm(g["cls"], axis=1)
     assert rel.max() < 1e-5, rel.max()
+
+
+HEAD_VARIANTS = [("h64_t63", dict(seq_len=63)), ("h64_t95", dict(seq_len=95)), ("h32", dict(lstm_hidden_size=32)),
+                 ("h96_t63", dict(lstm_hidden_size=96, seq_len=63)), ("h64_noacc", dict(use_acceleration=False)),
+                 ("h48_noacc_l2_t15", dict(use_acceleration=False, lstm_hidden_size=48, lstm_layers=2, seq_len=15))]
+
+
+@pytest.mark.parametrize("tag,kw", HEAD_VARIANTS, ids=[t for t, _ in HEAD_VARIANTS])
+def test_head_variant_goldens(golden_dir, tag, kw):
+    """Sequence lengths 63 / 95 (sweep_runner.py:110), other hidden sizes, use_acceleration=False: oracle vs reference."""
+    g = load(golden_dir, f"head_{tag}")
+    hc = C.HeadConfig(in_features=768, out_features=9, **kw)
+    hw = W.synth_head_weights(hc, 4321)
+    T = hc.seq_len
+    seq = synth.cls_walk(21, 48 + T - 1, 768).astype(np.float32)
+    x = np.stack([seq[i:i + T] for i in range(48)])
+    assert sha(x) == str(g["x_sha"])
+    logits, latent = H.head_forward(x, hw, seq_len=T)
+    np.testing.assert_allclose(logits, g["logits"], atol=3e-5)
+    np.testing.assert_allclose(latent, g["latent"], atol=2e-5)
+    assert (logits.argmax(1) == g["logits"].argmax(1)).all()
+
+
+@pytest.mark.parametrize("n,T", [(40, 63), (300, 63), (260, 95)])
+def test_infer_file_goldens_long_windows(golden_dir, n, T):
+    g = load(golden_dir, "infer_file_seq")
+    hw = W.synth_head_weights(C.HeadConfig(seq_len=T), 4321)
+    cls = synth.cls_walk(500 + n + T, n, 768)
+    assert sha(cls) == str(g[f"cls_sha_{n}_{T}"])
+    probs = PO.classify_cls(cls, hw, T, float(g[f"temp_{n}_{T}"]))
+    np.testing.assert_allclose(probs, g[f"probs_{n}_{T}"], atol=3e-6)
+    assert (probs.argmax(1) == g[f"probs_{n}_{T}"].argmax(1)).all()
