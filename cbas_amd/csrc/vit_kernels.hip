@@ -243,10 +243,19 @@ __device__ __forceinline__ void attn_store_f8(const f32x4 (&o)[4], float inv, ui
 // at compile time (T in ((NV-1)*16, NV*16]), 0 = decide per element at run time.  With NV fixed only the
 // ONE partial tile is masked (4 compares per lane, once) and fully padded tiles cost no MFMA; the
 // run-time form costs a compare+select per score because hipcc if-converts the tail test.
-template <int NKT, int NV>
-__global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
-                                                                            void* __restrict__ out_v, uint32_t* __restrict__ out_sc,
-                                                                            int sc_ld, int T, int D, int n_heads) {
+// SPLIT = 2 (the exact-T instantiations, full-frame mode): a (frame, head) pair is handled by TWO workgroups of 4
+// waves, one per half of the query tiles; both stage the pair's K and V.  With K + V = 52 KiB at T = 201 three such
+// workgroups share a CU, so 64 x 12 x 2 = 1 536 workgroups are exactly two full rounds over 256 CUs (one 7-wave
+// workgroup per pair was 1.5 rounds at two per CU), and the staging of one workgroup runs under the math of its
+// neighbours.  Workgroups b and b + 8 land on the same XCD (round-robin dispatch): the two halves of a pair are placed
+// 8 apart so the second K/V fetch hits that XCD's L2.
+// K and V are staged by 16-byte LDS-DMA (global_load_lds), all pieces in flight at once and no VGPR round trip; the
+// swizzles of the two images are applied on the SOURCE address (the LDS side of the DMA is lane-linear), rows past T
+// re-read row T-1 (finite values: their scores are masked, their probabilities exactly 0).
+template <int NKT, int NV, int SPLIT>
+__global__ __launch_bounds__(SPLIT == 2 ? 256 : 512, (SPLIT == 2 ? (NKT > 14 ? 2 : 3) : (NKT > 14 ? 2 : 4)))
+void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls, void* __restrict__ out_v,
+                      uint32_t* __restrict__ out_sc, int sc_ld, int T, int D, int n_heads, int n_pairs) {
     f16* __restrict__ out = reinterpret_cast<f16*>(out_v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = NKT * 16;
@@ -256,7 +265,13 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
     char* Vs = smem + ROWS * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int b = blockIdx.x / n_heads, hd = blockIdx.x - b * n_heads;
+    int pair = blockIdx.x, half = 0;
+    if (SPLIT == 2) {
+        pair = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7);
+        half = ((int)blockIdx.x >> 3) & 1;
+        if (pair >= n_pairs) return;                   // grid is padded to a multiple of 16
+    }
+    const int b = pair / n_heads, hd = pair - b * n_heads;
     const size_t ld = (size_t)3 * D;
     const f16* qbase = qkv + (size_t)b * T * ld + hd * 64;
     const f16* kbase = qbase + D;
@@ -267,7 +282,10 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
     const int nq = q_cls ? 1 : T;
     const f16* qsrc = q_cls ? q_cls + (size_t)b * D + hd * 64 : qbase;
     const size_t qld = q_cls ? 0 : ld;
-    const int nqt = (nq + 15) >> 4;
+    const int nqt_all = (nq + 15) >> 4;
+    const int q_per = SPLIT == 2 ? (nqt_all + 1) / 2 : nqt_all;         // query tiles of this workgroup: [qt0, nqt)
+    const int qt0 = half * q_per;
+    const int nqt = qt0 + q_per < nqt_all ? qt0 + q_per : nqt_all;
 
     auto load_q = [&](int qt, f16x8 (&qf)[2]) {
         const int q = qt * 16 + li;
@@ -277,20 +295,22 @@ __global__ __launch_bounds__(512, (NKT > 14 ? 2 : 4)) void attention_kernel(cons
     };
     // Q of this wave's first tile is fetched before the K/V staging so its latency hides under it
     f16x8 qf[2] = {}, qn[2] = {};
-    int qt = wave;
+    int qt = qt0 + wave;
     if (qt < nqt) load_q(qt, qf);
 
-    for (int idx = tid; idx < ROWS * 8; idx += blockDim.x) {
-        const int r = idx >> 3, c = idx & 7;
-        f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (r < T) {
-            kv = *reinterpret_cast<const f16x8*>(kbase + (size_t)r * ld + c * 8);
-            vv = *reinterpret_cast<const f16x8*>(vbase + (size_t)r * ld + c * 8);
+    {   // K / V staging: 1 KiB pieces (8 rows x 128 B) by LDS-DMA, piece p of each image to waves p mod nwaves
+        const int pr = lane >> 3, pos = lane & 7;
+        for (int p = wave; p < ROWS / 8; p += nwaves) {
+            const int r = p * 8 + pr;
+            const int rs = r < T ? r : T - 1;
+            const int kc = pos ^ ((r >> 1) & 7);                                   // k_off: chunk c sits at position c ^ swz
+            const int vc = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);       // v_off: 32-byte granules swizzled
+            __builtin_amdgcn_global_load_lds(GLB_PTR(kbase + (size_t)rs * ld + kc * 8), LDS_PTR(Ks + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(vbase + (size_t)rs * ld + vc * 8), LDS_PTR(Vs + p * 1024), 16, 0, 0);
         }
-        *reinterpret_cast<f16x8*>(Ks + k_off(r, c)) = kv;
-        *reinterpret_cast<f16x8*>(Vs + v_off(r, c * 8)) = vv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
-    __syncthreads();
 
     // Per-lane base addresses: the swizzles depend on (row & 15) / (row & 7) only, tile strides are
     // multiples of 16 rows, so every fragment read below is base + compile-time immediate.
@@ -524,23 +544,32 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
     }
 }
 
-template <int NKT, int NV>
+template <int NKT, int NV, int SPLIT>
 int launch_attention_t(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_sc, int sc_ld, int n, int T, int D, int n_heads,
                        hipStream_t stream) {
     constexpr int lds = NKT * 16 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT, NV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT, NV, SPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
+    }
+    if (SPLIT == 2) {                            // two 4-wave workgroups per (frame, head), grid padded to 16
+        const int pairs = n * n_heads;
+        hipLaunchKernelGGL((attention_kernel<NKT, NV, 2>), dim3(((pairs + 7) / 8) * 16), dim3(256), lds, stream, qkv, q_cls, out,
+                           out_sc, sc_ld, T, D, n_heads, pairs);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // at most 8 waves (a 1024-thread bound caps the kernel at 128 VGPRs and it spills); the fewest waves that keep
     // every wave equally loaded: T = 201 -> 13 tiles -> 7 waves x 2, T = 261 -> 17 tiles -> 6 waves x 3
     constexpr int maxw = 8;                  // measured: 13 waves x 1 tile (35 us) loses to 7 waves x 2 tiles (29.6 us) at T = 201
     const int nqt = (T + 15) / 16, rounds = (nqt + maxw - 1) / maxw;
-    const int nwaves = q_cls ? 4 : (nqt + rounds - 1) / rounds;       // CLS mode: one query tile, 4 waves stage K/V
-    hipLaunchKernelGGL((attention_kernel<NKT, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, q_cls, out, out_sc, sc_ld, T, D, n_heads);
+    static const int waves_env = [] { const char* e = getenv("CBAS_ATTN_WAVES"); return e ? atoi(e) : 0; }();      // experiments
+    int nwaves = q_cls ? 4 : (nqt + rounds - 1) / rounds;             // CLS mode: one query tile, 4 waves stage K/V
+    if (!q_cls && waves_env > 0 && waves_env <= 8) nwaves = waves_env;
+    hipLaunchKernelGGL((attention_kernel<NKT, NV, 1>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, q_cls, out, out_sc,
+                       sc_ld, T, D, n_heads, n * n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -676,12 +705,16 @@ int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_
     const int nkt = (T + 15) / 16;
     // exact-tile-count instantiations for the sequence lengths CBAS produces: 224x224 /16 -> T = 201 (13 tiles),
     // 256x256 /16 and 224x224 /14 -> T = 261 (17 tiles); everything else takes the run-time-masked form
-    if (nkt == 13) return launch_attention_t<14, 13>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
-    if (nkt == 17) return launch_attention_t<18, 17>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
-    if (nkt <= 2) return launch_attention_t<2, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
-    if (nkt <= 6) return launch_attention_t<6, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
-    if (nkt <= 14) return launch_attention_t<14, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
-    if (nkt <= 18) return launch_attention_t<18, 0>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    static const int split_env = [] { const char* e = getenv("CBAS_ATTN_SPLIT"); return e ? atoi(e) : 1; }();    // experiments
+    const bool split = split_env == 2 && !q_cls;
+    if (nkt == 13) return split ? launch_attention_t<14, 13, 2>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream)
+                                : launch_attention_t<14, 13, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt == 17) return split ? launch_attention_t<18, 17, 2>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream)
+                                : launch_attention_t<18, 17, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 2) return launch_attention_t<2, 0, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 6) return launch_attention_t<6, 0, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 14) return launch_attention_t<14, 0, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
+    if (nkt <= 18) return launch_attention_t<18, 0, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
     // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
     const int nqb = q_cls ? 1 : ((T + 15) / 16 + 7) / 8;
     hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D, n_heads);

@@ -14,10 +14,10 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    d = re.search(r"(gemm_f16_8ph_kernel|gemm_f16_kernel|attention_kernel|attention_stream_kernel|layernorm_f16_kernel)(<[^>]*>)?\(", name)
+    d = re.search(r"(gemm_f16_8ph_kernel|gemm_f16_kernel|attention_kernel|attention_stream_kernel|layernorm_f16_kernel|layernorm_f8_kernel)(<[^>]*>)?\(", name)
     if d:                                           # demangled form
         return d.group(1) + ((d.group(2) or "") if "gemm" in d.group(1) else "")
-    m = re.search(r"(\d+)(gemm_f16_8ph_kernel|gemm_f16_kernel|attention_kernel|attention_stream_kernel|layernorm_f16_kernel)(I[^v]*?E)?Ev", name)
+    m = re.search(r"(\d+)(gemm_f16_8ph_kernel|gemm_f16_kernel|attention_kernel|attention_stream_kernel|layernorm_f16_kernel|layernorm_f8_kernel)(I[^v]*?E)?Ev", name)
     if not m:
         return ""
     args = re.findall(r"Li(\d+)E", m.group(3) or "")
