@@ -187,7 +187,8 @@ int pick_tile(const GemmParams& p) {
     static const int forced = [] { const char* e = getenv("CBAS_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
     if (p.tile) return p.tile;
-    if (p.M <= 64 && !p.W_lo) return GEMM_TILE_64x128;
+    static const bool skinny_off = [] { const char* e = getenv("CBAS_GEMM_SKINNY"); return e && atoi(e) == 0; }();
+    if (p.M <= 64 && !p.W_lo) return skinny_off ? GEMM_TILE_64x128 : GEMM_TILE_SKINNY;
     // Measured with scripts/gemm_tiles.py at M = 12 864 (64 frames x 201 tokens), ViT-B shapes: the
     // 256x256 tile (16 waves, 1 workgroup per CU, 83 % MFMA-efficient main loop) wins on every
     // projection once there are enough tiles to occupy the chip; below that the 128x128 tile
@@ -214,6 +215,7 @@ int pick_tile(const GemmParams& p) {
 
 static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
     if (tile >= GEMM_TILE_PP_256x256 && tile <= GEMM_TILE_PP_AUTO) return launch_gemm_8ph(epi, p, tile, stream);
+    if (tile == GEMM_TILE_SKINNY) return launch_gemm_skinny(epi, p, stream);
     switch (epi) {
         case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
         case EPI_QKV:   return launch_epi<EPI_QKV>(p, tile, stream);

@@ -16,7 +16,7 @@ enum GemmEpilogue {
 
 enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2, GEMM_TILE_128x256 = 3,
                 GEMM_TILE_256x256 = 4,
-                GEMM_TILE_192x256 = 7, GEMM_TILE_64x128 = 8,
+                GEMM_TILE_192x256 = 7, GEMM_TILE_64x128 = 8, GEMM_TILE_SKINNY = 9,
                 GEMM_TILE_PP_256x256 = 13,      // gemm_f16_8ph.hip: 8 waves, ping-pong phases, counted vmcnt
                 GEMM_TILE_PP_192x256 = 14, GEMM_TILE_PP_160x256 = 15, GEMM_TILE_PP_128x256 = 16,
                 GEMM_TILE_PP_AUTO = 17 };       // planner: uniform tile height, or 256-row tiles + 128-row tail
@@ -65,6 +65,7 @@ struct GemmParams {
 
 int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
+int launch_gemm_skinny(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);     // M <= 64 (gemm_f16_skinny.hip)
 
 // ---------------------------------------------------------------------------------------------
 // ViT element-wise / attention kernels

@@ -10,7 +10,7 @@ from cbas_amd import _lib
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(300, 256, 128), (1000, 512, 256), (257, 256, 4096), (5000, 1024, 1024), (12864, 768, 768), (6432, 3072, 768),
-          (12864, 2304, 768), (32928, 1024, 1024), (1, 256, 768)]
+          (12864, 2304, 768), (32928, 1024, 1024), (1, 256, 768), (64, 768, 3072), (37, 3072, 768)]
 TILES = [4, 7, 13, 14, 15, 16, 17]
 
 
@@ -27,5 +27,5 @@ def test_tile_variants_are_bit_identical(shape):
 
     ref = run(1)
     assert ref != 0
-    for t in TILES:
+    for t in TILES + ([8, 9] if m <= 64 else []):            # 64x128 and the skinny ring kernel for the CLS-row GEMMs
         assert run(t) == ref, (shape, t)
