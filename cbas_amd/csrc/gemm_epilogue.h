@@ -136,6 +136,60 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
             if (i + 2 < TM) load_x(i + 2, xs[i & 1]);
             asm volatile("" ::: "memory");
         }
+    } else if (EPI == EPI_GELU_F8) {
+        // MX-fp8 output (precision 2): quantise in the ACCUMULATOR layout, then transpose bytes.  A lane holds, for row
+        // li of a 16-row tile, columns j*16 + g*4 + e (j, e = 0..3): the 32-column scale block b is j in {2b, 2b+1} over the
+        // four lanes g = 0..3 with equal li, i.e. an in-lane max over 8 values and two shuffles.  The wave's 64 columns
+        // are blocks (head_col0 % 128) / 32 + {0, 1} of K-tile head_col0 / 128 of the consumer (the down projection).
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + head_col0 + j * 16 + g * 4);
+        pre();
+        uint8_t* const sc_bytes = reinterpret_cast<uint8_t*>(p.out_sc) + (size_t)(head_col0 >> 7) * p.sc_ldo * 4 + ((head_col0 & 127) >> 5);
+#pragma unroll
+        for (int half = 0; half < (TM + 3) / 4; ++half) {              // up to 64 rows per pass: 64 x 64 bytes of scratch
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = half * 4 + ii;
+                if (i >= TM) break;
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = acc[i][j] + bv[j];
+                    v[j] = f32x4{gelu_fast(w[0]), gelu_fast(w[1]), gelu_fast(w[2]), gelu_fast(w[3])};
+                }
+                int sb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fmaxf(a, fmaxf(fabsf(v[2 * b][e]), fabsf(v[2 * b + 1][e])));
+                    a = fmaxf(a, __shfl_xor(a, 16, 64));
+                    a = fmaxf(a, __shfl_xor(a, 32, 64));
+                    sb[b] = mx_scale_byte(a);
+                }
+                const int rl = ii * 16 + li;                            // row within the 64-row pass
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float inv = mx_inv_scale(sb[j >> 1]);
+                    // 16-byte chunk j of the row sits at position j ^ ((rl >> 1) & 3): ds_write_b32 at most 2-way conflicted
+                    *reinterpret_cast<unsigned*>(scratch + rl * 64 + ((j ^ ((rl >> 1) & 3)) << 4) + g * 4) =
+                        cvt4_e4m3(v[j][0] * inv, v[j][1] * inv, v[j][2] * inv, v[j][3] * inv);
+                }
+                const int m = row_base + i * 16 + li;
+                if (g == 0 && m < p.M) *reinterpret_cast<uint16_t*>(sc_bytes + (size_t)m * 4) = (uint16_t)(sb[0] | (sb[1] << 8));
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (it * 16 >= (TM - half * 4) * 16) break;             // rows of this pass (compile-time)
+                const int r = it * 16 + (lane >> 2), c = lane & 3;      // 16 rows x 64 bytes per wave store
+                const uint4 q = *reinterpret_cast<const uint4*>(scratch + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
+                const int m = row_base + half * 64 + r;
+                if (m < p.M) *reinterpret_cast<uint4*>(p.out_f8 + (size_t)m * p.ldo + head_col0 + c * 16) = q;
+            }
+            asm volatile("" ::: "memory");
+        }
     } else {                                     // EPI_QKV / EPI_GELU: fp16 out, whole 64x(TM*16) tile at once
         f32x4 bv[4];
 #pragma unroll
@@ -195,29 +249,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const int r = it * 8 + (lane >> 3), c = lane & 7;      // 8 rows x 128 bytes per wave store
                 const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = row_base + half * 64 + r;
-                if (EPI == EPI_GELU_F8) {
-                    // MX-fp8 store: the lane holds 8 consecutive columns of row m; a 32-column scale block is the 4 lanes
-                    // c = 0..3 (or 4..7).  The wave's 64 columns are blocks (head_col0 % 128) / 32 + {0, 1} of K-tile
-                    // head_col0 / 128 of the consumer (the down projection).
-                    float f[8], a = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { f[e] = (float)hv[e]; a = fmaxf(a, fabsf(f[e])); }
-                    a = fmaxf(a, __shfl_xor(a, 1, 64));
-                    a = fmaxf(a, __shfl_xor(a, 2, 64));
-                    const int sb = mx_scale_byte(a);
-                    const float inv = mx_inv_scale(sb);
-                    const int sb_hi = __shfl_xor(sb, 4, 64);
-                    uint2 q;
-                    q.x = cvt4_e4m3(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
-                    q.y = cvt4_e4m3(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
-                    if (m < p.M) {
-                        *reinterpret_cast<uint2*>(p.out_f8 + (size_t)m * p.ldo + head_col0 + c * 8) = q;
-                        if (c == 0)
-                            *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(p.out_sc) +
-                                                         ((size_t)(head_col0 >> 7) * p.sc_ldo + m) * 4 + ((head_col0 & 127) >> 5)) =
-                                (uint16_t)(sb | (sb_hi << 8));
-                    }
-                } else {
+                {
                     if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
                 }
             }
