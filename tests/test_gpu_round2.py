@@ -349,3 +349,50 @@ def test_encode_files_world1_equals_encode_file(tmp_path):
         P.set_project_stamp(None)
         head.close()
         enc.close()
+
+
+def test_encode_files_cli_single_process(tmp_path, capsys):
+    """`python -m cbas_amd.encode_files --encoder <ckpt> --model-bundle <dir> videos...` (the N-GPU queue entry point)
+    run in-process at world 1: checkpoint dir + bundle in, `_cls.h5` with the encoder stamp and `_outputs.csv` with the
+    bundle's behaviours and calibration temperature out; `--dir` picks up only videos lacking an up-to-date `_cls.h5`."""
+    import os
+    from cbas_amd import bundle as B, encode_files as EF, h5io, pipeline as P
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from oracle import pipeline_oracle as PO
+    cfg = C.ViTConfig(hidden_size=768, intermediate_size=1536, num_hidden_layers=1, num_attention_heads=12, image_size=32)
+    enc_w = W.synth_encoder_weights(cfg, 1234)
+    ck = str(tmp_path / "ckpt")
+    W.save_encoder_checkpoint(ck, cfg, enc_w)
+    names = ["a", "b", "c"]
+    hcfg = C.HeadConfig(out_features=3)
+    hw = W.synth_head_weights(hcfg, 5)
+    head = ClassifierLSTMDeltas(768, 3)
+    head.load_state_dict(hw)
+    B.save_model_bundle(str(tmp_path / "mymodel"), head, names, "mymodel", ck, temperature=1.3)
+    rec = tmp_path / "rec"
+    rec.mkdir()
+    fr = synth.cage_frames(8, 90, 32, 32)
+    np.save(str(rec / "v0.npy"), fr)
+    try:
+        rc = EF.main(["--encoder", ck, "--model-bundle", str(tmp_path / "mymodel"), "--max-batch", "32",
+                      "--max-frame", "32", "32", str(rec / "v0.npy")])
+        assert rc == 0
+        with h5io.ClsReader(str(rec / "v0_cls.h5")) as r:
+            assert r.shape == (90, 768) and r.attrs["encoder_model_identifier"] == ck
+            rows = r.read(0, 90)
+        got = np.loadtxt(str(rec / "v0_mymodel_outputs.csv"), delimiter=",", skiprows=1, dtype=np.float32)
+        assert open(str(rec / "v0_mymodel_outputs.csv")).readline().strip() == "a,b,c"
+        np.testing.assert_allclose(got, PO.classify_cls(rows, hw, 31, 1.3), atol=1e-4)
+        ref = PO.encode_frames(fr, enc_w, cfg, batch=8)
+        rel = np.linalg.norm(rows.astype(np.float32) - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert rel.max() < 1.5e-3
+        # --dir semantics (startup_page.py:92-117): an encoded, correctly stamped video is not queued again
+        assert EF.find_videos(str(rec), ck) == []
+        os.rename(str(rec / "v0.npy"), str(rec / "v0.mp4"))
+        os.rename(str(rec / "v0_cls.h5"), str(rec / "v0_cls.h5.bak"))
+        assert EF.find_videos(str(rec), ck) == [str(rec / "v0.mp4")]
+        os.rename(str(rec / "v0_cls.h5.bak"), str(rec / "v0_cls.h5"))
+        assert EF.find_videos(str(rec), ck) == [] and EF.find_videos(str(rec), "another-encoder") == [str(rec / "v0.mp4")]
+    finally:
+        P.set_project_stamp(None)
+        head.close()
