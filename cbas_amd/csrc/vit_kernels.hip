@@ -205,6 +205,14 @@ __global__ __launch_bounds__(256) void final_norm_cls_kernel(const float* __rest
 // V is read through ds_read_b64_tr_b16 (hardware transpose) as the A operand, giving O^T with 4
 // consecutive head dims per lane (one 8-byte store per tile).
 // ---------------------------------------------------------------------------------------------
+// max of three without the canonicalising v_max_f32 x,x that hipcc puts in front of fmaxf on MFMA outputs (one extra
+// VALU instruction per score in kernels that are VALU-bound: PMC in DESIGN.md); no NaNs occur here
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int row, int col) {   // col in halves
     return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
@@ -352,7 +360,8 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
             }
-            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            mx = max3_raw(mx, s[kt][0], s[kt][1]);
+            mx = max3_raw(mx, s[kt][2], s[kt][3]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -544,6 +553,147 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming variant, second form (r2): the same per-wave arithmetic with KT key tiles (16*KT keys) per block, K/V
+// blocks staged by 16-byte LDS-DMA into a 2-deep ring (no VGPR round trip, no LDS-write pass) and ONE raw barrier
+// per block: iteration kb waits for its own pieces of block kb (vmcnt(0): they were issued one iteration earlier),
+// joins the barrier (every wave's pieces have landed AND every wave is done reading the other buffer), issues block
+// kb+1 into that other buffer and computes on block kb.  Twice the keys per block halve the barriers and the online
+// softmax rescales and double the independent MFMA chains in flight (the kernel is dependency-bound: PMC in DESIGN.md).
+// Rows past T re-read row T-1 (finite; their scores are masked to -inf before the max).
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(512, 2) void attention_stream2_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
+                                                                   void* __restrict__ out_v, uint32_t* __restrict__ out_sc, int sc_ld,
+                                                                   int T, int D, int n_heads) {
+    constexpr int KB = KT * 16;                                  // keys per block
+    constexpr int BLK = KB * 128;                                // bytes of one K (or V) block image
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * BLK];   // [buf][K | V][KB keys][128 B]
+    f16* __restrict__ out = reinterpret_cast<f16*>(out_v);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / n_heads, hd = blockIdx.x - b * n_heads;
+    const size_t ld = (size_t)3 * D;
+    const f16* qbase = qkv + (size_t)b * T * ld + hd * 64;
+    const f16* kbase = qbase + D;
+    const f16* vbase = qbase + 2 * D;
+    const int g = lane >> 4, li = lane & 15;
+    const int nkb = (T + KB - 1) / KB;
+    const int q = (blockIdx.y * 8 + wave) * 16 + li;
+    const int nq = q_cls ? 1 : T;                              // CLS-query mode: see attention_kernel
+    const bool wave_active = (blockIdx.y * 8 + wave) * 16 < nq;   // wave-uniform; idle waves still stage K/V
+    const int qrow = q < nq ? q : nq - 1;
+    const f16* qsrc = q_cls ? q_cls + (size_t)b * D + hd * 64 : qbase + (size_t)qrow * ld;
+    f16x8 qf[2];
+    qf[0] = *reinterpret_cast<const f16x8*>(qsrc + g * 8);
+    qf[1] = *reinterpret_cast<const f16x8*>(qsrc + 32 + g * 8);
+
+    // staging: KB/8 pieces of 1 KiB per image, piece p to wave p mod 8 (KT = 8: two K and two V pieces per wave)
+    const int pr = lane >> 3, pos = lane & 7;
+    auto stage = [&](int kb) {
+        char* Kd = smem + (kb & 1) * 2 * BLK;
+        char* Vd = Kd + BLK;
+#pragma unroll
+        for (int s2 = 0; s2 < KB / 64; ++s2) {
+            const int p = wave + 8 * s2;
+            const int r = p * 8 + pr;                            // row within the block
+            int gr = kb * KB + r;
+            gr = gr < T ? gr : T - 1;
+            const int kc = pos ^ ((r >> 1) & 7);
+            const int vc = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(kbase + (size_t)gr * ld + kc * 8), LDS_PTR(Kd + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(vbase + (size_t)gr * ld + vc * 8), LDS_PTR(Vd + p * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of block kb
+        __builtin_amdgcn_s_barrier();                            // everyone's; and buffer (kb+1)&1 is free
+        if (kb + 1 < nkb) stage(kb + 1);
+        const char* Ks = smem + (kb & 1) * 2 * BLK;
+        const char* Vs = Ks + BLK;
+        if (wave_active) {
+            f32x4 s[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(Ks + k_off(kt * 16 + li, g)), qf[0], acc, 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(Ks + k_off(kt * 16 + li, 4 + g)), qf[1], acc, 0, 0, 0);
+            }
+            if (kb == nkb - 1) {                                 // only the last block can hold keys past T (scalar branch)
+                const int k0 = kb * KB + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + kt * 16 + r >= T) s[kt][r] = -INFINITY;
+            }
+            float bm = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                bm = max3_raw(bm, s[kt][0], s[kt][1]);
+                bm = max3_raw(bm, s[kt][2], s[kt][3]);
+            }
+            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float m_new = fmaxf(m, bm);                    // finite: block 0 always holds key 0
+            const float alpha = __builtin_amdgcn_exp2f((m - m_new) * 1.4426950408889634f);
+            const float m2 = m_new * 1.4426950408889634f;
+            m = m_new;
+            float bs = 0.f;
+            f16x8 pf[KT / 2];
+#pragma unroll
+            for (int grp = 0; grp < KT / 2; ++grp) {
+                f32x4 e0, e1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e0[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp][r], 1.4426950408889634f, -m2));
+                    e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1][r], 1.4426950408889634f, -m2));
+                }
+                bs += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
+                pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
+            }
+            l = l * alpha + bs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < KT / 2; ++s2) {
+                const int krow = 32 * s2 + 4 * g + (li >> 2);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int col = 16 * dt + 4 * (li & 3);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow, col)));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Vs + v_off(krow + 16, col)));
+                    union { struct { s16x4 a, b; } s; f16x8 v; } u;
+                    u.s.a = lo; u.s.b = hi;
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[s2], o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (out_sc) {
+        if (wave_active) attn_store_f8(o, 1.0f / l, reinterpret_cast<uint8_t*>(out_v), out_sc, sc_ld, (size_t)b * T + q, q < nq, D, hd, g);
+    } else if (q < nq) {
+        const float inv = 1.0f / l;
+        f16* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 w = o[dt] * inv;
+            f16x4 hv = {(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
+            *reinterpret_cast<f16x4*>(orow + 16 * dt) = hv;
+        }
+    }
+}
+
 template <int NKT, int NV, int SPLIT>
 int launch_attention_t(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_sc, int sc_ld, int n, int T, int D, int n_heads,
                        hipStream_t stream) {
@@ -717,6 +867,17 @@ int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_
     if (nkt <= 18) return launch_attention_t<18, 0, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
     // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
     const int nqb = q_cls ? 1 : ((T + 15) / 16 + 7) / 8;
+    static const int stream_env = [] { const char* e = getenv("CBAS_ATTN_STREAM"); return e ? atoi(e) : 2; }();   // 1: first form
+    if (stream_env == 2) {
+        hipLaunchKernelGGL(attention_stream2_kernel<8>, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
+                           n_heads);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (stream_env == 3) {
+        hipLaunchKernelGGL(attention_stream2_kernel<4>, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
+                           n_heads);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     hipLaunchKernelGGL(attention_stream_kernel, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D, n_heads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
