@@ -83,6 +83,8 @@ struct ExpandArgs {
     const float* ln_b;       // [3 Bn]
     const float* b_lin1;     // [C]
     int T, Bn, NPROJ, C;
+    int big;                 // long windows (seq_len 63 / 95: sweep_runner.py:110): only U lives in LDS, the projected rows
+                             // and the temporal matrices are read from global memory (same fma order: same bits)
     unsigned long long key[3];
     unsigned thr; float scale;
 };
@@ -91,14 +93,22 @@ __global__ __launch_bounds__(768) void train_expand_fwd_kernel(ExpandArgs a, flo
                                                                float* __restrict__ lin_logits) {
     extern __shared__ float sm[];
     const int T = a.T, Bn = a.Bn, F = 3 * Bn, NP = a.NPROJ;
-    float* P = sm;                       // [T][NP]
-    float* TM = P + T * NP;              // [3][T][T]
-    float* U = TM + 3 * T * T;           // [T][F]
     const int64_t w = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < T * NP; i += blockDim.x) P[i] = a.proj[w * T * NP + i];
-    for (int i = tid; i < 3 * T * T; i += blockDim.x) TM[i] = a.tmat[i];
-    __syncthreads();
+    const float* P;                      // [T][NP]
+    const float* TM;                     // [3][T][T]
+    float* U;                            // [T][F]
+    if (a.big) {
+        P = a.proj + w * T * NP; TM = a.tmat; U = sm;
+    } else {
+        float* Pl = sm;
+        float* TMl = Pl + T * NP;
+        U = TMl + 3 * T * T;
+        for (int i = tid; i < T * NP; i += blockDim.x) Pl[i] = a.proj[w * T * NP + i];
+        for (int i = tid; i < 3 * T * T; i += blockDim.x) TMl[i] = a.tmat[i];
+        __syncthreads();
+        P = Pl; TM = TMl;
+    }
     if (tid < F) {
         const int k = tid / Bn;
         const float bias = a.b_bott[tid];
@@ -142,12 +152,19 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
                                                                float* __restrict__ dproj, float* __restrict__ part) {
     extern __shared__ float sm[];
     const int T = a.T, Bn = a.Bn, F = 3 * Bn, NP = a.NPROJ;
-    float* TM = sm;                      // [3][T][T]
-    float* U = TM + 3 * T * T;           // [T][F]   dropped GELU outputs (LayerNorm inputs)
-    float* ST = U + T * F;               // [3T][4]  mean, rstd, sum(dxhat)/Bn, sum(dxhat*xhat)/Bn
     const int64_t w = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * T * T; i += blockDim.x) TM[i] = a.tmat[i];
+    const float* TM;                     // [3][T][T]
+    float* U;                            // [T][F]   dropped GELU outputs (LayerNorm inputs)
+    if (a.big) {
+        TM = a.tmat; U = sm;
+    } else {
+        float* TMl = sm;
+        U = TMl + 3 * T * T;
+        for (int i = tid; i < 3 * T * T; i += blockDim.x) TMl[i] = a.tmat[i];
+        TM = TMl;
+    }
+    float* ST = U + T * F;               // [3T][4]  mean, rstd, sum(dxhat)/Bn, sum(dxhat*xhat)/Bn
     const int k = tid < F ? tid / Bn : 0;
     if (tid < F) {
         for (int t = 0; t < T; ++t) {
@@ -553,9 +570,18 @@ static ExpandArgs make_expand_args(const TrainExpandParams& p) {
 }
 static int expand_block(const TrainExpandParams& p) { return (int)round_up(3 * p.Bn, 64); }
 
+// LDS bytes of the expand kernels: everything resident when it fits, otherwise the "big" form (U + row statistics only)
+static size_t expand_lds(int T, int Bn, int NPROJ, bool fwd, bool big) {
+    if (big) return ((size_t)T * 3 * Bn + 12 * (size_t)T) * 4;
+    return fwd ? ((size_t)T * NPROJ + 3 * (size_t)T * T + (size_t)T * 3 * Bn) * 4
+               : (3 * (size_t)T * T + (size_t)T * 3 * Bn + 12 * (size_t)T) * 4;
+}
+static bool expand_big(int T, int Bn, int NPROJ) {
+    return expand_lds(T, Bn, NPROJ, true, false) > 160 * 1024 || expand_lds(T, Bn, NPROJ, false, false) > 160 * 1024;
+}
 size_t train_expand_lds_bytes(int T, int Bn, int NPROJ) {
-    const size_t fwd = ((size_t)T * NPROJ + 3 * (size_t)T * T + (size_t)T * 3 * Bn) * 4;
-    const size_t bwd = (3 * (size_t)T * T + (size_t)T * 3 * Bn + 12 * (size_t)T) * 4;
+    const bool big = expand_big(T, Bn, NPROJ);
+    const size_t fwd = expand_lds(T, Bn, NPROJ, true, big), bwd = expand_lds(T, Bn, NPROJ, false, big);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -563,7 +589,8 @@ int launch_train_expand_fwd(const TrainExpandParams& p, int64_t n_windows, float
                             hipStream_t st) {
     const int block = expand_block(p);
     if (block > 768 || p.C > 3 * p.Bn) return -1;
-    const size_t lds = ((size_t)p.T * p.NPROJ + 3 * (size_t)p.T * p.T + (size_t)p.T * 3 * p.Bn) * 4;
+    const bool big = expand_big(p.T, p.Bn, p.NPROJ);
+    const size_t lds = expand_lds(p.T, p.Bn, p.NPROJ, true, big);
     if (lds > 160 * 1024) return -1;
     static bool attr = false;
     if (!attr) {
@@ -571,8 +598,9 @@ int launch_train_expand_fwd(const TrainExpandParams& p, int64_t n_windows, float
                                 160 * 1024) != hipSuccess) return -2;
         attr = true;
     }
-    hipLaunchKernelGGL(train_expand_fwd_kernel, dim3((unsigned)n_windows), dim3(block), lds, st, make_expand_args(p), Y, aug,
-                       lin_logits);
+    ExpandArgs ea = make_expand_args(p);
+    ea.big = big ? 1 : 0;
+    hipLaunchKernelGGL(train_expand_fwd_kernel, dim3((unsigned)n_windows), dim3(block), lds, st, ea, Y, aug, lin_logits);
     return CHECK_LAUNCH();
 }
 
@@ -580,7 +608,8 @@ int launch_train_expand_bwd(const TrainExpandParams& p, int64_t n_windows, const
                             float* dproj, float* part, hipStream_t st) {
     const int block = expand_block(p);
     if (block > 768) return -1;
-    const size_t lds = (3 * (size_t)p.T * p.T + (size_t)p.T * 3 * p.Bn + 12 * (size_t)p.T) * 4;
+    const bool big = expand_big(p.T, p.Bn, p.NPROJ);
+    const size_t lds = expand_lds(p.T, p.Bn, p.NPROJ, false, big);
     if (lds > 160 * 1024) return -1;
     static bool attr = false;
     if (!attr) {
@@ -588,8 +617,9 @@ int launch_train_expand_bwd(const TrainExpandParams& p, int64_t n_windows, const
                                 160 * 1024) != hipSuccess) return -2;
         attr = true;
     }
-    hipLaunchKernelGGL(train_expand_bwd_kernel, dim3((unsigned)n_windows), dim3(block), lds, st, make_expand_args(p), Y, daug,
-                       dlin, dproj, part);
+    ExpandArgs ea = make_expand_args(p);
+    ea.big = big ? 1 : 0;
+    hipLaunchKernelGGL(train_expand_bwd_kernel, dim3((unsigned)n_windows), dim3(block), lds, st, ea, Y, daug, dlin, dproj, part);
     return CHECK_LAUNCH();
 }
 

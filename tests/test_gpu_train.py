@@ -182,9 +182,12 @@ def test_train_lstm_model_shim_runs_the_reference_loop():
     model.close()
 
 
-@pytest.mark.parametrize("I,Cn,T,h,nl,B", [(384, 4, 15, 64, 1, 20), (768, 12, 41, 128, 2, 9)])
+@pytest.mark.parametrize("I,Cn,T,h,nl,B", [(384, 4, 15, 64, 1, 20), (768, 12, 41, 128, 2, 9),
+                                           (768, 9, 63, 64, 1, 10), (768, 5, 95, 128, 1, 6)])     # sweep_runner.py:110 lengths
 def test_other_shapes_against_oracle(I, Cn, T, h, nl, B):
-    """ViT-S width / short windows / 12 classes / long windows with a stacked h=128 LSTM: gradients vs float64 autograd."""
+    """ViT-S width / short windows / 12 classes / long windows with a stacked h=128 LSTM / the sweep's 63- and 95-frame
+    windows (the expand kernels then keep only U in LDS and read the projected rows from global memory): gradients vs
+    float64 autograd."""
     from oracle import head_train_oracle as HT
     hcfg = C.HeadConfig(in_features=I, out_features=Cn, seq_len=T, lstm_hidden_size=h, lstm_layers=nl)
     hw = W.synth_head_weights(hcfg, 99)
