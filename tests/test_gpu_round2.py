@@ -396,3 +396,65 @@ def test_encode_files_cli_single_process(tmp_path, capsys):
     finally:
         P.set_project_stamp(None)
         head.close()
+
+
+def _dist_rank(rank, world, port, td, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from cbas_amd import dist as cdist, pipeline as P
+    from cbas_amd.head import ClassifierLSTMDeltas
+    cdist.init_from_env("gloo")                       # two ranks share the one GPU of the test box: rows travel through gloo
+    cfg, enc = _enc("tiny", 16, (64, 64))
+    head = ClassifierLSTMDeltas(cfg.hidden_size, 4)
+    head.load_state_dict(W.synth_head_weights(C.HeadConfig(in_features=cfg.hidden_size, out_features=4), 3))
+    head.to("cuda")
+    P.set_project_stamp("enc-id")
+    paths = [os.path.join(td, f"v{i}.npy") for i in range(5)]
+    recs = cdist.encode_files(paths, enc, head=head, dataset_name="ds", behaviors=["a", "b", "c", "d"], temperature=0.7)
+    if rank == 0:
+        q.put(recs)
+    dist.barrier()
+    head.close()
+    enc.close()
+    dist.destroy_process_group()
+
+
+def test_encode_files_two_ranks_real_kernels(tmp_path):
+    """Two processes (gloo) driving the real encoder / head on the one GPU: rank 0's files are byte-identical to the
+    single-process encode_file / infer_file results."""
+    import hashlib, os, shutil, socket
+    import torch.multiprocessing as mp
+    from cbas_amd import pipeline as P
+    from cbas_amd.head import ClassifierLSTMDeltas
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()          # noqa: E731
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    for i, n in enumerate((50, 0, 530, 31, 64)):
+        np.save(str(a / f"v{i}.npy"), synth.cage_frames(70 + i, n, 64, 64))
+        shutil.copy(str(a / f"v{i}.npy"), str(b / f"v{i}.npy"))
+    cfg, enc = _enc("tiny", 16, (64, 64))
+    head = ClassifierLSTMDeltas(cfg.hidden_size, 4)
+    head.load_state_dict(W.synth_head_weights(C.HeadConfig(in_features=cfg.hidden_size, out_features=4), 3))
+    head.to("cuda")
+    P.set_project_stamp("enc-id")
+    exp = []
+    for i in range(5):
+        h5 = P.encode_file(enc, str(a / f"v{i}.npy"))
+        exp.append(None if h5 is None else (sha(h5), sha(P.infer_file(h5, head, "ds", ["a", "b", "c", "d"], 31, device="cuda", temperature=0.7))))
+    P.set_project_stamp(None)
+    head.close(); enc.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, str(b), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    recs = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r["status"] for r in recs] == ["ok", "empty", "ok", "ok", "ok"]
+    for r, e in zip(recs, exp):
+        if e is not None:
+            assert (sha(r["cls_file"]), sha(r["csv_file"])) == e, r["path"]
