@@ -93,8 +93,12 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     const int wr = wave >> 2, wc = wave & 3;
     const int nk = p.K / (F8 ? 2 * BK : BK);           // even, >= 2 (checked by the launcher)
     constexpr int ESZ = F8 ? 1 : 2;                    // bytes per operand element: a K-tile is always 128 bytes per row
-    const char* Abase = F8 ? reinterpret_cast<const char*>(p.A8) : reinterpret_cast<const char*>(p.A);
-    const char* Wbase = F8 ? reinterpret_cast<const char*>(p.W8) : reinterpret_cast<const char*>(p.W);
+    // operands are addressed through buffer descriptors (SGPRs) + a 32-bit per-lane offset + a scalar K-tile offset:
+    // no 64-bit address arithmetic per LDS-DMA, fewer VGPRs (what lets a LayerNorm wave of the other lane share a SIMD)
+    const __amdgpu_buffer_rsrc_t Arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(F8 ? reinterpret_cast<const void*>(p.A8) : reinterpret_cast<const void*>(p.A)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(F8 ? reinterpret_cast<const void*>(p.W8) : reinterpret_cast<const void*>(p.W)), 0, 0x7fffffff, 0x00020000);
     char* const sc_lds = smem + pp_lds_main<TA, TB>(); // F8: [buf][A rows 256 x 4 B | B rows 256 x 4 B]
 
     // ---- LDS-DMA source offsets: two 8-row pieces per wave and sub-tile --------------------------
@@ -106,8 +110,10 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     unsigned a_src[2][2], b_src[2][2];
     // F8: block scales of one K-tile.  Waves 0-3 fetch the dwords of A rows row0 + 64*wave + lane, waves 4-7 those of
     // W rows col0 + 64*(wave-4) + lane (rows past the tile / past M_pad are clamped or belong to a neighbour: never used)
-    const uint32_t* sc_src = nullptr;
-    const int sc_step = F8 ? (wave < 4 ? p.sc_lda : (p.sc_ldw ? p.sc_ldw : p.N)) : 0, sc_dst = wave * 256;
+    unsigned sc_src = 0;                               // byte offset into A_sc (waves 0-3) / W_sc (waves 4-7)
+    const int sc_step = F8 ? 4 * (wave < 4 ? p.sc_lda : (p.sc_ldw ? p.sc_ldw : p.N)) : 0, sc_dst = wave * 256;   // bytes per K-tile
+    const __amdgpu_buffer_rsrc_t Srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(wave < 4 ? p.A_sc : p.W_sc)), 0, 0x7fffffff, 0x00020000);
     auto set_tile = [&](int id) {
         const int lrow = lane >> 3;
         const int bid = gemm_xcd_remap(id, n_kind);
@@ -137,9 +143,9 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
             if (wave < 4) {
                 int r = row0 + wave * 64 + lane;
                 r = r < p.M_pad - 1 ? r : p.M_pad - 1;
-                sc_src = p.A_sc + r;
+                sc_src = (unsigned)r * 4u;
             } else {
-                sc_src = p.W_sc + col0 + (wave - 4) * 64 + lane;
+                sc_src = (unsigned)(col0 + (wave - 4) * 64 + lane) * 4u;
             }
         }
     };
@@ -151,13 +157,13 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         if (which & 1) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(Abase + a_src[h][s] + kt * 128), LDS_PTR(base + a_lds[h][s]), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Arsrc, LDS_PTR(base + a_lds[h][s]), 16, a_src[h][s], kt * 128, 0, 0);
             if (F8 && h == 1)        // rides with A-sub1: retired by the same counted vmcnt, two barriers before its first read
-                __builtin_amdgcn_global_load_lds(GLB_PTR(sc_src + (size_t)kt * sc_step), LDS_PTR(sc_lds + buf * 2048 + sc_dst), 4, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Srsrc, LDS_PTR(sc_lds + buf * 2048 + sc_dst), 4, sc_src, kt * sc_step, 0, 0);
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(Wbase + b_src[h][s] + kt * 128), LDS_PTR(base + b_lds[h][s]), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Wrsrc, LDS_PTR(base + b_lds[h][s]), 16, b_src[h][s], kt * 128, 0, 0);
         }
     };
 
