@@ -1063,24 +1063,24 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (ms_out) *ms_out = ms / iters;
     if (want_stamps) {
-        const int nblk = 16384;
+        const int nblk = GEMM_STAMP_BLOCKS;
         unsigned long long* st = nullptr;
-        HIP_TRY(hipMalloc(&st, (size_t)nblk * 32));
-        HIP_TRY(hipMemset(st, 0, (size_t)nblk * 32));
+        HIP_TRY(hipMalloc(&st, (size_t)nblk * 40));
+        HIP_TRY(hipMemset(st, 0, (size_t)nblk * 40));
         p.stamps = st;
-        launch_gemm(epi, p, 0);
+        launch_gemm(epi, p, 0);                  // straight after the timed launches: the clock is the loaded one
         HIP_TRY(hipDeviceSynchronize());
-        std::vector<unsigned long long> hs((size_t)nblk * 4);
-        HIP_TRY(hipMemcpy(hs.data(), st, (size_t)nblk * 32, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, t1 = 0; double pro = 0, loop = 0, epi_c = 0; int n = 0;
+        std::vector<unsigned long long> hs((size_t)nblk * 5);
+        HIP_TRY(hipMemcpy(hs.data(), st, (size_t)nblk * 40, hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi_c = 0, real = 0; int n = 0;
         for (int b = 0; b < nblk; ++b) {
             if (!hs[4 * b + 3]) continue;
-            t0 = std::min(t0, hs[4 * b]); t1 = std::max(t1, hs[4 * b + 3]);
             pro += (double)(hs[4 * b + 1] - hs[4 * b]); loop += (double)(hs[4 * b + 2] - hs[4 * b + 1]);
-            epi_c += (double)(hs[4 * b + 3] - hs[4 * b + 2]); ++n;
+            epi_c += (double)(hs[4 * b + 3] - hs[4 * b + 2]); real += (double)hs[(size_t)nblk * 4 + b]; ++n;
         }
-        printf("  stamps: %d blocks, kernel span %.0f ticks; per block avg prologue %.0f, loop %.0f, epilogue %.0f ticks (100 MHz ticks)\n",
-               n, (double)(t1 - t0), pro / n, loop / n, epi_c / n);
+        // s_memtime ticks are shader cycles; the K loop's span in s_memrealtime (100 MHz) ticks gives the in-kernel clock
+        printf("  stamps (first tile of each workgroup): %d workgroups; avg prologue %.0f, K loop %.0f, epilogue %.0f cycles; "
+               "in-kernel clock %.2f GHz\n", n, pro / n, loop / n, epi_c / n, real > 0 ? loop / real * 0.1 : 0.0);
         fflush(stdout);
         p.stamps = nullptr;
         hipFree(st);

@@ -66,7 +66,8 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
             const int n = ncol + j * 16;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
             const f32x4 w = acc[j] + bv;
-            const f16x4 hv = {(f16)gelu_fast(w[0]), (f16)gelu_fast(w[1]), (f16)gelu_fast(w[2]), (f16)gelu_fast(w[3])};
+            const f32x4 gv = gelu_fast4(w);
+            const f16x4 hv = {(f16)gv[0], (f16)gv[1], (f16)gv[2], (f16)gv[3]};
             *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldo + n) = hv;
         }
     }
@@ -156,7 +157,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 w = acc[i][j] + bv[j];
-                    v[j] = f32x4{gelu_fast(w[0]), gelu_fast(w[1]), gelu_fast(w[2]), gelu_fast(w[3])};
+                    v[j] = gelu_fast4(w);
                 }
                 int sb[2];
 #pragma unroll
@@ -232,7 +233,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        v[j] = f32x4{gelu_fast(v[j][0]), gelu_fast(v[j][1]), gelu_fast(v[j][2]), gelu_fast(v[j][3])};
+                        v[j] = gelu_fast4(v[j]);
                 }
                 const int rl = ii * 16 + li;                            // row within the 64-row pass
 #pragma unroll

@@ -117,7 +117,20 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     auto set_tile = [&](int id) {
         const int lrow = lane >> 3;
         const int bid = gemm_xcd_remap(id, n_kind);
-        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        int tm, tn;
+        if (p.group_m > 1) {
+            // grouped raster: group_m row panels x all column tiles, row-fastest, so that the ~32 tiles an XCD runs at
+            // a time form a squarish block (operand footprint per round (rows + cols) x 256 x K instead of a few
+            // rows x every column)
+            const int width = p.group_m * tiles_n, grp = bid / width, in = bid - grp * width;
+            const int m0 = grp * p.group_m, left = n_kind / tiles_n - m0;
+            const int gsz = left < p.group_m ? left : p.group_m;
+            tn = in / gsz;
+            tm = m0 + in - tn * gsz;
+        } else {
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
         row0 = base_row + tm * BM;
         col0 = tn * BN;
 #pragma unroll
@@ -183,7 +196,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     };
 
     f32x4 acc[TM][4];
-    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0, r_pro = 0, r_loop = 0;   // r_*: s_memrealtime (100 MHz)
     if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
     stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3);      // K-tile 0 of the first tile
 
@@ -309,7 +322,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         stage(1, 1, 0); stage(1, 1, 1); stage(1, 1, 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (p.stamps && id == first) t_pro = __builtin_amdgcn_s_memtime();
+        if (p.stamps && id == first) { t_pro = __builtin_amdgcn_s_memtime(); r_pro = __builtin_amdgcn_s_memrealtime(); }
         if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
 
         for (int t = 0; t < nk; t += 2) {
@@ -318,7 +331,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the groups: every wave has now left the loop
 
-        if (p.stamps && id == first) t_loop = __builtin_amdgcn_s_memtime();
+        if (p.stamps && id == first) { t_loop = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
         const int erow = row0 + wr * WROWS, ecol = col0 + wc * 64;
         const int next = id + stride;
         const bool has_next = next < n_kind;
@@ -332,6 +345,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
             o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
+            p.stamps[(size_t)GEMM_STAMP_BLOCKS * 4 + blockIdx.x] = r_loop - r_pro;     // in-kernel clock = loop ticks / this x 100 MHz
         }
         if (!has_next) break;
         id = next;

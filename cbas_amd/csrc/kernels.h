@@ -21,6 +21,7 @@ enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2
                 GEMM_TILE_PP_192x256 = 14, GEMM_TILE_PP_160x256 = 15, GEMM_TILE_PP_128x256 = 16,
                 GEMM_TILE_PP_AUTO = 17 };       // planner: uniform tile height, or 256-row tiles + 128-row tail
 
+constexpr int GEMM_STAMP_BLOCKS = 16384;     // GemmParams::stamps: [GEMM_STAMP_BLOCKS][4] s_memtime stamps + [GEMM_STAMP_BLOCKS] loop spans in s_memrealtime ticks
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)
     int group_m;         // raster: row-panels per group (0/1 = N-fastest order)

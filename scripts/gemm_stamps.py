@@ -6,11 +6,12 @@ lib = _lib.load()
 fn = lib.cbas_debug_gemm_bench
 fn.restype = C.c_int
 fn.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
-tiles = [int(t) for t in sys.argv[1].split(",")]
-M = 12864
+tiles = [int(t) for t in sys.argv[1].split(",")]           # usage: gemm_stamps.py 13,17 [iters [M]]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 12864
 for name, m, n, k, eoff in [("qkv/up-like gelu", M, 3072, 768, 0), ("oproj", M, 768, 768, 100), ("down", M, 768, 3072, 100)]:
     for t in tiles:
         ms, cs = C.c_float(), C.c_ulonglong()
         print(f"{name} tile {t}:", flush=True)
-        rc = fn(m, n, k, 1000 + t + eoff, 20, C.byref(ms), C.byref(cs))
+        rc = fn(m, n, k, 1000 + t + eoff, iters, C.byref(ms), C.byref(cs))
         print(f"   {ms.value*1e3:.1f} us rc={rc}", flush=True)
