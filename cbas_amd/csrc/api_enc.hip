@@ -1020,11 +1020,15 @@ __global__ void checksum_u16(const uint16_t* p, int64_t n, unsigned long long* o
 
 extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
                                      unsigned long long* checksum_out) {
-    // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100
+    // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100;
+    // tile >= 200: q|k|v epilogue (RoPE tables of 196 patches, 201 tokens per frame, D = N / 3) with tile id = tile - 200
     const bool want_stamps = tile >= 1000;   // 1000 + tile: also print the block timeline statistics
     tile %= 1000;
-    const bool resid = tile >= 100;
+    const bool qkv = tile >= 200;
+    const bool resid = !qkv && tile >= 100;
+    if (qkv) tile -= 200;
     if (resid) tile -= 100;
+    if (qkv && (N % 3 || (N / 3) % 64)) return cbas_fail(CBAS_EINVAL, "q|k|v bench needs N = 3 D, D a multiple of 64");
     if (M <= 0 || N % 128 || K % 64 || iters <= 0) return cbas_fail(CBAS_EINVAL, "bad GEMM bench shape");
     const int64_t M_pad = round_up(M, 256);
     f16 *A = nullptr, *Wt = nullptr, *out = nullptr;
@@ -1048,7 +1052,17 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
         HIP_TRY(hipMemset(x32, 0, M_pad * (int64_t)N * 4));
         p.out_f32 = x32; p.lambda = bias;      // lambda = 0: x stays 0, timing only
     }
-    const GemmEpilogue epi = resid ? EPI_RESID : EPI_GELU;
+    float* rope = nullptr;
+    if (qkv) {
+        HIP_TRY(hipMalloc(&rope, 2 * 196 * 64 * 4));
+        HIP_TRY(hipMemset(rope, 0, 2 * 196 * 64 * 4));
+        p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3; p.tokens_per_frame = 201; p.n_prefix = 5;
+    }
+    const GemmEpilogue epi = qkv ? EPI_QKV : resid ? EPI_RESID : EPI_GELU;
+    if (epi == EPI_GELU) {                       // experiment builds (-DCBAS_EXP_EPI) read flag bits here; unused otherwise
+        const char* e = getenv("CBAS_EXP_FLAGS");
+        p.n_prefix = e ? atoi(e) : 0;
+    }
     int rc = launch_gemm(epi, p, 0);
     if (rc) return cbas_fail(CBAS_EINVAL, "launch_gemm failed for tile %d (rc=%d)", tile, rc);
     HIP_TRY(hipDeviceSynchronize());
@@ -1088,7 +1102,7 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     hipLaunchKernelGGL(checksum_u16, dim3(1024), dim3(256), 0, 0, (const uint16_t*)out, (int64_t)M * N, cs);
     if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, cs, 8, hipMemcpyDeviceToHost));
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32);
+    hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32); if (rope) hipFree(rope);
     return CBAS_OK;
 }
 

@@ -231,9 +231,13 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                         for (int j = 0; j < 4; ++j) v[j] = v[j] * qs;
                     }
                 } else {
+#ifdef CBAS_EXP_EPI
+                    if (!(p.n_prefix & 1))
+#endif
+                    {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[j] = gelu_fast4(v[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_fast4(v[j]);
+                    }
                 }
                 const int rl = ii * 16 + li;                            // row within the 64-row pass
 #pragma unroll
@@ -251,7 +255,10 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = row_base + half * 64 + r;
                 {
-                    if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
+#ifdef CBAS_EXP_EPI
+                if (EPI == EPI_GELU && (p.n_prefix & 2) && m >= 0) continue;
+#endif
+                if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
                 }
             }
             asm volatile("" ::: "memory");
