@@ -74,11 +74,13 @@ struct cbas_enc {
     // grid gets FRESH device buffers filled by a blocking copy, so no stream has to be drained when a queue mixes
     // resolutions; rope_cos / rope_sin / pos_tab point at the set of the batch being queued (kernel arguments are
     // captured at launch).  Only when POS_TABLES_MAX grids are cached is the oldest one recycled behind a device sync.
-    struct PosTable { int nh = 0, nw = 0; float *cos = nullptr, *sin = nullptr, *pos = nullptr; uint64_t last_use = 0; };
+    struct PosTable { int nh = 0, nw = 0; float *cos = nullptr, *sin = nullptr, *fac = nullptr, *pos = nullptr; uint64_t last_use = 0; };
     static constexpr int POS_TABLES_MAX = 8;
     std::vector<PosTable> pos_tables;
     uint64_t pos_clock = 0;
     float *rope_cos = nullptr, *rope_sin = nullptr;
+    float* rope_fac = nullptr;          // the same angles by axis, [nh + nw][cos(16) | sin(16)] (GemmParams::rope_fac)
+    int rope_nh = 0, rope_nw = 0;
     int rope_cap = 0;
     // workspaces
     int64_t rows_cap = 0, prow_cap = 0;
@@ -163,6 +165,7 @@ int acquire_pos_table(cbas_enc* h, int nh, int nw, cbas_enc::PosTable** out) {
         if (h->cfg.use_rope) {
             HIP_TRY(hipMalloc(&t->cos, Pmax * 64 * sizeof(float)));
             HIP_TRY(hipMalloc(&t->sin, Pmax * 64 * sizeof(float)));
+            HIP_TRY(hipMalloc(&t->fac, (Pmax + 1) * 32 * sizeof(float)));     // nh + nw <= nh * nw + 1
         } else {
             HIP_TRY(hipMalloc(&t->pos, Pmax * h->D * sizeof(float)));
         }
@@ -224,7 +227,7 @@ int ensure_rope(cbas_enc* h, int nh, int nw) {
     cbas_enc::PosTable* t = nullptr;
     const int rc = acquire_pos_table(h, nh, nw, &t);
     if (rc < 0) return rc;
-    h->rope_cos = t->cos; h->rope_sin = t->sin;
+    h->rope_cos = t->cos; h->rope_sin = t->sin; h->rope_fac = t->fac; h->rope_nh = nh; h->rope_nw = nw;
     if (rc == 0) return CBAS_OK;
     const int P = nh * nw;
     // [tf]:96-121 patch-centre coordinates, :153-200 angles; float32 throughout like the reference
@@ -247,8 +250,29 @@ int ensure_rope(cbas_enc* h, int nh, int nw) {
         }
     HIP_TRY(hipMemcpy(t->cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));       // blocking; nothing reads t yet
     HIP_TRY(hipMemcpy(t->sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    // the same numbers by axis: columns 0-15 of patch (iy, ix) are those of any patch in row iy, 16-31 of column ix
+    std::vector<float> fac((size_t)(nh + nw) * 32);
+    for (int iy = 0; iy < nh; ++iy)
+        for (int d = 0; d < 16; ++d) {
+            fac[(size_t)iy * 32 + d] = c[(size_t)(iy * nw) * 64 + d];
+            fac[(size_t)iy * 32 + 16 + d] = s[(size_t)(iy * nw) * 64 + d];
+        }
+    for (int ix = 0; ix < nw; ++ix)
+        for (int d = 0; d < 16; ++d) {
+            fac[(size_t)(nh + ix) * 32 + d] = c[(size_t)ix * 64 + 16 + d];
+            fac[(size_t)(nh + ix) * 32 + 16 + d] = s[(size_t)ix * 64 + 16 + d];
+        }
+    HIP_TRY(hipMemcpy(t->fac, fac.data(), fac.size() * 4, hipMemcpyHostToDevice));
     t->nh = nh; t->nw = nw;
     return CBAS_OK;
+}
+
+// RoPE tables of the grid ensure_rope() selected, into the q|k|v GEMM's parameters
+void set_rope(const cbas_enc* h, GemmParams& p) {
+    if (!h->cfg.use_rope) return;
+    p.rope_cos = h->rope_cos; p.rope_sin = h->rope_sin;
+    p.rope_fac = h->rope_fac; p.rope_nh = h->rope_nh; p.rope_nw = h->rope_nw;
+    p.rope_magic = (unsigned)((1ull << 32) / (unsigned)h->rope_nw) + 1u;
 }
 
 int check_frame(cbas_enc* h, int n, int height, int width) {
@@ -307,7 +331,7 @@ int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t s
     }
     kv.M = M; kv.M_pad = M_pad; kv.N = 2 * D; kv.K = D; kv.bias = w.qkv_b + D; kv.out_f16 = h->qkv16 + D; kv.ldo = 3 * D;
     kv.tokens_per_frame = T; kv.n_prefix = h->NP; kv.D = D; kv.sec0 = 1;
-    kv.rope_cos = h->cfg.use_rope ? h->rope_cos : nullptr; kv.rope_sin = h->cfg.use_rope ? h->rope_sin : nullptr;
+    set_rope(h, kv);
     { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, kv, st)); }
     GemmParams q{};                         // q section, CLS rows only (row b*T of h16; the compact fp16 rows when f8)
     q.A = f8 ? hc : h->h16; q.lda = f8 ? D : T * D; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr;
@@ -378,7 +402,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
         else { q.A = h->h16; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr; }
         q.M = M; q.M_pad = M_pad; q.N = 3 * D; q.K = D; q.bias = w.qkv_b; q.out_f16 = h->qkv16; q.ldo = 3 * D;
         q.tokens_per_frame = T; q.n_prefix = h->NP; q.D = D;
-        q.rope_cos = h->cfg.use_rope ? h->rope_cos : nullptr; q.rope_sin = h->cfg.use_rope ? h->rope_sin : nullptr;
+        set_rope(h, q);
         { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
         if (stop(2)) return CBAS_OK;
 
@@ -478,7 +502,7 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
                       h->lanes[1].sc_h, h->lanes[1].sc_u};
         for (void* b : b1) if (b) (void)hipFree(b);
     }
-    for (auto& t : h->pos_tables) { if (t.cos) (void)hipFree(t.cos); if (t.sin) (void)hipFree(t.sin); if (t.pos) (void)hipFree(t.pos); }
+    for (auto& t : h->pos_tables) { if (t.cos) (void)hipFree(t.cos); if (t.sin) (void)hipFree(t.sin); if (t.fac) (void)hipFree(t.fac); if (t.pos) (void)hipFree(t.pos); }
     void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->prefix_dev,
                     h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16, h->w8, h->w8_sc, h->sc_h, h->sc_u};
     for (void* b : bufs)
@@ -1057,6 +1081,10 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
         HIP_TRY(hipMalloc(&rope, 2 * 196 * 64 * 4));
         HIP_TRY(hipMemset(rope, 0, 2 * 196 * 64 * 4));
         p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3; p.tokens_per_frame = 201; p.n_prefix = 5;
+        p.rope_fac = rope; p.rope_nh = 14; p.rope_nw = 14; p.rope_magic = (unsigned)((1ull << 32) / 14u) + 1u;   // zeros: timing only
+        const char* e = getenv("CBAS_EXP_FLAGS");
+        if (e && (atoi(e) & 4)) p.rope_cos = p.rope_sin = nullptr;       // timing experiment: the epilogue without RoPE
+        if (e && (atoi(e) & 8)) p.rope_fac = nullptr;                    // ... and with the global [P][64] table
     }
     const GemmEpilogue epi = qkv ? EPI_QKV : resid ? EPI_RESID : EPI_GELU;
     if (epi == EPI_GELU) {                       // experiment builds (-DCBAS_EXP_EPI) read flag bits here; unused otherwise

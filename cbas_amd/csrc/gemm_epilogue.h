@@ -7,6 +7,17 @@
 #pragma once
 #include "kernels.h"
 
+// a * c + b * s with the rounding fixed - one product rounded, then one fma - so that every kernel variant and both
+// epilogue forms give the same bits whatever the compiler would have contracted
+__device__ __forceinline__ f32x4 rope_rot(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
+    f32x4 t;
+    {
+#pragma clang fp contract(off)
+        t = b * s;
+    }
+    return __builtin_elementwise_fma(a, c, t);
+}
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, int head_col0, int lane,
                                                   const f32x4 (&acc)[4]) {
@@ -38,7 +49,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
                 const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
                 const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
                 // rotate_half(x)[d] = -x[d+32] (d < 32), x[d-32] (d >= 32)
-                o[j] = (j < 2) ? (v[j] * c - v[j + 2] * s) : (v[j] * c + v[j - 2] * s);
+                o[j] = (j < 2) ? rope_rot(v[j], c, v[j + 2], -s) : rope_rot(v[j], c, v[j - 2], s);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = o[j];
@@ -82,13 +93,17 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
 // global access is whole 128-byte (fp16) / 256-byte (fp32) row segments.
 //   scratch: 8 KiB per wave, 16-byte aligned, wave-private (in-order LDS => no barrier needed).
 // ---------------------------------------------------------------------------------------------
+#ifndef CBAS_EPI_PASS_SLABS
+#define CBAS_EPI_PASS_SLABS 1
+#endif
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
 // `pre` is called once, after the epilogue's first global loads have been issued (they would otherwise queue behind
 // it): the persistent kernel issues the next tile's first LDS-DMAs there.
 template <int EPI, int TM, typename Pre = NoPrefetch>
 __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_base, int head_col0, int lane,
-                                                   const f32x4 (&acc)[TM][4], char* scratch, Pre pre = Pre()) {
+                                                   const f32x4 (&acc)[TM][4], char* scratch, Pre pre = Pre(),
+                                                   const float* rope_lds = nullptr) {
     const int li = lane & 15, g = lane >> 4;
     if (EPI == EPI_PATCH) {                      // small GEMM with a row scatter: keep the direct form
         pre();
@@ -197,35 +212,70 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
         for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + head_col0 + j * 16 + g * 4);
         const int sec = (EPI == EPI_QKV) ? head_col0 / p.D + p.sec0 : 2;
         const float qs = (sec == 0) ? 0.125f : 1.0f;
+        // RoPE (q and k sections).  From the global [P][64] table this was 256 KB of L2 reads per 256x256 tile (every wave
+        // of a row group fetches the same rows, and 8 waves x 4 KB per slab do not live in the 16 KB L1): 7-9k of the
+        // epilogue's 16k cycles, bound by the ~30 B/cycle/CU L2 rate, not by latency (fetching two slabs ahead changed
+        // nothing).  The angles factorise by axis ([tf]:96-121: columns 0-15 use the patch row, 16-31 the patch column),
+        // so the ping-pong kernel keeps (nh + nw) x 128 bytes in LDS and reads the same numbers from there (rope_lds).
+        // The table is angles.tile(2) ([tf]:190): columns d and d+32 hold the same value, so two loads per table serve
+        // all four 16-column groups.  Prefix rows (cls + registers) are not rotated: they read row 0, keep their values.
+        const bool rope = EPI == EPI_QKV && p.rope_cos && sec < 2;
+        f32x4 rcs[2][2], rsn[2][2];
+        bool rot[2] = {false, false};
+        int t_row = rope ? (row_base + li) % p.tokens_per_frame : 0;   // token index of this lane's row in the slab being fetched
+        auto load_rope = [&](int slot) {
+            const int pr = t_row - p.n_prefix;
+            rot[slot] = pr >= 0;
+            const int pp = pr > 0 ? pr : 0;
+            if (rope_lds) {
+                const int iy = (int)__umulhi((unsigned)pp, p.rope_magic), ix = pp - iy * p.rope_nw;
+                const float* ry = rope_lds + iy * 32 + g * 4;
+                const float* rx = rope_lds + (p.rope_nh + ix) * 32 + g * 4;
+                rcs[slot][0] = *reinterpret_cast<const f32x4*>(ry);
+                rsn[slot][0] = *reinterpret_cast<const f32x4*>(ry + 16);
+                rcs[slot][1] = *reinterpret_cast<const f32x4*>(rx);
+                rsn[slot][1] = *reinterpret_cast<const f32x4*>(rx + 16);
+            } else {
+                const size_t ro = (size_t)pp * 64 + g * 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    rcs[slot][j] = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
+                    rsn[slot][j] = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
+                }
+            }
+            t_row += 16;                                                // next slab: 16 rows further
+            if (p.tokens_per_frame >= 16) t_row -= t_row >= p.tokens_per_frame ? p.tokens_per_frame : 0;
+            else t_row %= p.tokens_per_frame;
+        };
+        if (rope) {
+            load_rope(0);
+            if (TM > 1) load_rope(1);
+        }
         pre();
+        // PS slabs of 16 rows per pass through the scratch (two alternating regions: the LDS is in order per wave, so a
+        // pass may overwrite what the pass before last has read).  PS = 1: the stores of a slab are in flight while
+        // the next slab's arithmetic runs, and only the last slab's stores are exposed.
+        constexpr int PS = CBAS_EPI_PASS_SLABS;
 #pragma unroll
-        for (int half = 0; half < (TM + 3) / 4; ++half) {              // up to 64 rows per pass (8 KiB of scratch)
+        for (int half = 0; half < (TM + PS - 1) / PS; ++half) {
+            char* const sc = scratch + (half & 1) * (PS * 2048);
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int i = half * 4 + ii;
-                if (i >= TM) break;                                     // compile-time after unrolling (TM = 6: 4 + 2 slabs)
+            for (int ii = 0; ii < PS; ++ii) {
+                const int i = half * PS + ii;
+                if (i >= TM) break;                                     // compile-time after unrolling
                 f32x4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
                 if (EPI == EPI_QKV) {
-                    const int m = row_base + i * 16 + li;
-                    const int t = m % p.tokens_per_frame;
-                    if (p.rope_cos && sec < 2 && t >= p.n_prefix) {
-                        // the table is angles.tile(2) ([tf]:190): columns d and d+32 hold the same value,
-                        // so two loads per table serve all four 16-column groups
-                        const size_t ro = (size_t)(t - p.n_prefix) * 64 + g * 4;
-                        f32x4 cs[2], sn[2];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            cs[j] = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
-                            sn[j] = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
-                        }
+                    if (rope) {
+                        const int sl = i & 1;
                         f32x4 o[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            o[j] = (j < 2) ? (v[j] * cs[j] - v[j + 2] * sn[j]) : (v[j] * cs[j - 2] + v[j - 2] * sn[j - 2]);
+                            o[j] = (j < 2) ? rope_rot(v[j], rcs[sl][j], v[j + 2], -rsn[sl][j]) : rope_rot(v[j], rcs[sl][j - 2], v[j - 2], rsn[sl][j - 2]);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = o[j] * qs;
+                        for (int j = 0; j < 4; ++j) v[j] = (rot[sl] ? o[j] : v[j]) * qs;
+                        if (i + 2 < TM) load_rope(sl);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = v[j] * qs;
@@ -244,16 +294,16 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 for (int j = 0; j < 4; ++j) {
                     const int q = (4 * j + g) ^ ((rl & 7) << 1);        // 8-byte granule swizzle, pairs stay adjacent
                     const f16x4 hv = {(f16)v[j][0], (f16)v[j][1], (f16)v[j][2], (f16)v[j][3]};
-                    *reinterpret_cast<f16x4*>(scratch + rl * 128 + q * 8) = hv;
+                    *reinterpret_cast<f16x4*>(sc + rl * 128 + q * 8) = hv;
                 }
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                if (it * 8 >= (TM - half * 4) * 16) break;              // rows of this pass (compile-time)
+                if (it * 8 >= PS * 16 || it * 8 >= (TM - half * PS) * 16) break;   // rows of this pass (compile-time)
                 const int r = it * 8 + (lane >> 3), c = lane & 7;      // 8 rows x 128 bytes per wave store
-                const f16x8 hv = *reinterpret_cast<const f16x8*>(scratch + r * 128 + ((c ^ (r & 7)) << 4));
-                const int m = row_base + half * 64 + r;
+                const f16x8 hv = *reinterpret_cast<const f16x8*>(sc + r * 128 + ((c ^ (r & 7)) << 4));
+                const int m = row_base + half * (PS * 16) + r;
                 {
 #ifdef CBAS_EXP_EPI
                 if (EPI == EPI_GELU && (p.n_prefix & 2) && m >= 0) continue;

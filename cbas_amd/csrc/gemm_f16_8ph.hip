@@ -71,12 +71,18 @@ constexpr int pp_lds_main() {
     return 2 * buf > buf + 65536 ? 2 * buf : buf + 65536;
 }
 
+// staging buffers (+ MX scale images) of a kernel instantiation: what lies in front of the q|k|v kernel's RoPE table
+template <int TA, int TB, int TAIL, bool F8>
+constexpr int pp_lds_kernel() {
+    return (TAIL && pp_lds_main<2, 2>() > pp_lds_main<TA, TB>() ? pp_lds_main<2, 2>() : pp_lds_main<TA, TB>()) + (F8 ? 4096 : 0);
+}
+
 // Runs the tiles `first, first + stride, ...` (< n_kind) of one kind: tile id -> (tm, tn) through the XCD remap over
 // n_kind ids; rows start at base_row.  Persistent: while a tile's epilogue runs, the LDS-DMA of the NEXT tile's first
 // K-tile is already in flight into buffer 0 (its latency - most of the prologue - hides under the epilogue).
 template <int EPI, int TA, int TB, bool F8>
 __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int first, int n_kind, int stride, int base_row,
-                                         int tiles_n) {
+                                         int tiles_n, const float* rope_lds) {
     constexpr int TM = TA + TB;                      // 16-row MFMA tiles per wave
     constexpr int WROWS = 16 * TM;                   // rows of C per wave
     constexpr int BM = 2 * WROWS;
@@ -340,7 +346,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         // every wave is past the loop: buffer 0 is free, and the scratch below lies over buffer 1
         gemm_epilogue_tile<EPI, TM>(p, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
             if (has_next) { stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
-        });
+        }, rope_lds);
         if (p.stamps && id == first && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
@@ -363,15 +369,25 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N / BN;
     const int G = gridDim.x;                                   // a multiple of 8 whenever a workgroup gets > 1 tile
+    // q|k|v: the factorised RoPE table lives in LDS behind the staging buffers for the life of the workgroup
+    const float* rope_lds = nullptr;
+    if (EPI == EPI_QKV && p.rope_fac) {
+        float* dst = reinterpret_cast<float*>(smem + pp_lds_kernel<TA, TB, TAIL, F8>());
+        const int n4 = (p.rope_nh + p.rope_nw) * 8;            // 16-byte pieces
+        for (int i = threadIdx.x; i < n4; i += 512)
+            reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(p.rope_fac)[i];
+        __syncthreads();
+        rope_lds = dst;
+    }
     int first = blockIdx.x;
     if (first < g.main_blocks) {
-        pp_tiles<EPI, TA, TB, F8>(p, smem, first, g.main_blocks, G, 0, tiles_n);
+        pp_tiles<EPI, TA, TB, F8>(p, smem, first, g.main_blocks, G, 0, tiles_n, rope_lds);
         first += ((g.main_blocks - 1 - first) / G + 1) * G;    // this workgroup's first id past the main tiles
     }
     if (TAIL && first < g.n_tiles) {
         // the first tail tile's K-tile 0 is not prefetched across the kind switch: drain the LDS before restaging
         __syncthreads();
-        pp_tiles<EPI, 2, 2, F8>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n);
+        pp_tiles<EPI, 2, 2, F8>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n, rope_lds);
     }
 }
 
@@ -387,8 +403,7 @@ int pp_cus() {
 template <int EPI, int TA, int TB, int TAIL, bool F8>
 int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     constexpr int BM = 32 * (TA + TB);
-    constexpr int lds_main = TAIL && pp_lds_main<2, 2>() > pp_lds_main<TA, TB>() ? pp_lds_main<2, 2>() : pp_lds_main<TA, TB>();
-    constexpr int lds = lds_main + (F8 ? 4096 : 0);
+    constexpr int lds = pp_lds_kernel<TA, TB, TAIL, F8>() + (EPI == EPI_QKV ? ROPE_LDS_ROWS * 128 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -490,7 +505,9 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
 
 }  // namespace
 
-int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
+int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p_in, int tile, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (p.rope_fac && (!p.rope_cos || p.rope_nw <= 1 || p.rope_nh + p.rope_nw > ROPE_LDS_ROWS)) p.rope_fac = nullptr;   // global table
     // 32-bit byte offsets into A / W; K-tiles are consumed in pairs
     if (p.W_lo || p.N % 256 || (long long)p.M_pad * p.lda >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31)) return -1;
     if (p.A8) {                                        // MX-fp8 operands: 128-element K-tiles

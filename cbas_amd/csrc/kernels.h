@@ -22,6 +22,7 @@ enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2
                 GEMM_TILE_PP_AUTO = 17 };       // planner: uniform tile height, or 256-row tiles + 128-row tail
 
 constexpr int GEMM_STAMP_BLOCKS = 16384;     // GemmParams::stamps: [GEMM_STAMP_BLOCKS][4] s_memtime stamps + [GEMM_STAMP_BLOCKS] loop spans in s_memrealtime ticks
+constexpr int ROPE_LDS_ROWS = 192;            // (nh + nw) rows of 128 bytes the q|k|v kernel holds in LDS (24 KiB)
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)
     int group_m;         // raster: row-panels per group (0/1 = N-fastest order)
@@ -60,6 +61,12 @@ struct GemmParams {
     // EPI_QKV
     const float* rope_cos;   // [P][64], or nullptr: no RoPE (DINOv2)
     const float* rope_sin;   // [P][64]
+    // the same numbers factorised by axis (columns 0-15 of a table row depend on the patch row only, 16-31 on the patch
+    // column only): [nh + nw][32] floats, row r < nh = {cos(16) | sin(16)} of patch row r, row nh + c = those of patch
+    // column c.  The ping-pong kernel keeps this copy in LDS (nullptr, or more than ROPE_LDS_ROWS rows: global table).
+    const float* rope_fac;
+    int rope_nh, rope_nw;
+    unsigned rope_magic;     // floor(2^32 / rope_nw) + 1: patch row = umulhi(patch, rope_magic)
     int D;                   // hidden size (q | k | v sections of width D)
     int sec0;                // section of output column 0 (0: the full q|k|v GEMM; 1: W holds only k|v)
 };
