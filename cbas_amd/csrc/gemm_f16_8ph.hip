@@ -429,7 +429,10 @@ int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     static const int persist = [] { const char* e = getenv("CBAS_PP_PERSIST"); return e ? atoi(e) : 1; }();
     const int slots = pp_cus() & ~7;
     const int grid = persist && g.n_tiles > slots ? slots : g.n_tiles;
-    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>), dim3(grid), dim3(512), lds, stream, p, g);
+    // the launch asks only for the table rows this grid has (224^2: 3.5 KiB), not the ROPE_LDS_ROWS the attribute allows:
+    // what is left of the 160 KiB decides which kernels of the other compute lane can share the CU
+    const int lds_launch = pp_lds_kernel<TA, TB, TAIL, F8>() + (EPI == EPI_QKV && p.rope_fac ? (p.rope_nh + p.rope_nw) * 128 : 0);
+    hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>), dim3(grid), dim3(512), lds_launch, stream, p, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
