@@ -510,7 +510,10 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
 
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p_in, int tile, hipStream_t stream) {
     GemmParams p = p_in;
-    if (p.rope_fac && (!p.rope_cos || p.rope_nw <= 1 || p.rope_nh + p.rope_nw > ROPE_LDS_ROWS)) p.rope_fac = nullptr;   // global table
+    if (p.rope_fac) {                                   // the LDS copy of the RoPE table, or the global [P][64] table
+        const char* e = getenv("CBAS_ROPE_LDS");        // read per launch: tests switch it to compare the two forms
+        if ((e && e[0] == '0') || !p.rope_cos || p.rope_nw <= 1 || p.rope_nh + p.rope_nw > ROPE_LDS_ROWS) p.rope_fac = nullptr;
+    }
     // 32-bit byte offsets into A / W; K-tiles are consumed in pairs
     if (p.W_lo || p.N % 256 || (long long)p.M_pad * p.lda >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31)) return -1;
     if (p.A8) {                                        // MX-fp8 operands: 128-element K-tiles

@@ -7,6 +7,8 @@
 * a queue that mixes resolutions needs no device synchronisation and stays correct;
 * two synchronous forwards on different caller streams are ordered by the library.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -458,3 +460,31 @@ def test_encode_files_two_ranks_real_kernels(tmp_path):
     for r, e in zip(recs, exp):
         if e is not None:
             assert (sha(r["cls_file"]), sha(r["csv_file"])) == e, r["path"]
+
+
+@pytest.mark.parametrize("hw", [(160, 224), (224, 96), (64, 16)])
+def test_rope_table_in_lds_equals_global_table_and_the_oracle(hw):
+    """The q|k|v GEMM of the ping-pong kernel rotates with the RoPE angles factorised by axis and held in LDS
+    (gemm_epilogue.h); the [P][64] table in global memory is the fallback (one patch column, or more than
+    ROPE_LDS_ROWS rows).  Same numbers either way: bit-identical outputs on non-square grids, and within the CLS
+    tolerance of the CPU restatement of [tf] modeling_dinov3_vit.py:96-121,168-200."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.NAMED_VIT["vitb16"]
+    w = W.synth_encoder_weights(cfg, 1234)
+    fr = synth.cage_frames(5, 3, *hw)
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=4, max_frame=hw)
+    try:
+        a16, a32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+        os.environ["CBAS_ROPE_LDS"] = "0"
+        try:
+            b16, b32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+        finally:
+            del os.environ["CBAS_ROPE_LDS"]
+        torch.cuda.synchronize()
+        assert torch.equal(a32, b32) and torch.equal(a16, b16)
+        ref = PO.encode_frames(fr[:2], w, cfg, batch=2)
+        rel = np.linalg.norm(a32[:2].cpu().numpy() - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert rel.max() < 1e-3, rel
+    finally:
+        enc.close()
