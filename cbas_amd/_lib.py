@@ -66,6 +66,7 @@ SIGNATURES = {
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int, c_int]),
     "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_debug_overlap": (c_int, [c_int, c_int, C.POINTER(c_float)]),
     "cbas_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float),
                                       C.POINTER(C.c_ulonglong)]),
     "cbas_debug_gemm_f8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -8,6 +8,7 @@
 
 #include "api_common.h"
 #include "kernels.h"
+#include <chrono>
 
 thread_local char g_cbas_err[512] = {0};
 
@@ -1131,6 +1132,57 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, cs, 8, hipMemcpyDeviceToHost));
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32); if (rope) hipFree(rope);
+    return CBAS_OK;
+}
+
+// Bring-up: how kernels of two compute lanes share the chip.  Runs, each on its own stream and concurrently, `iters`
+// launches of: bit 0 the up projection (12 864 x 3072 x 768, GELU epilogue), bit 1 LayerNorm (12 864 x 768), bit 2 the
+// resident attention kernel (64 frames x 201 tokens, 12 heads), bit 3 the down projection (residual epilogue);
+// ms_out[b] = average time per launch of component b as seen on its stream, ms_out[4] = wall time of the whole run.
+extern "C" int cbas_debug_overlap(int mode, int iters, float* ms_out) {
+    if (iters <= 0 || !ms_out) return cbas_fail(CBAS_EINVAL, "bad arguments");
+    const int n = 64, T = 201, D = 768, F = 3072, M = n * T;
+    const int64_t M_pad = round_up(M, 256);
+    f16 *h16 = nullptr, *u16 = nullptr, *qkv = nullptr, *ctx = nullptr, *Wu = nullptr, *Wd = nullptr, *ln_out = nullptr;
+    float *x = nullptr, *x2 = nullptr, *vec = nullptr;
+    HIP_TRY(hipMalloc(&h16, M_pad * D * 2)); HIP_TRY(hipMalloc(&u16, M_pad * (int64_t)F * 2));
+    HIP_TRY(hipMalloc(&qkv, M_pad * 3 * D * 2)); HIP_TRY(hipMalloc(&ctx, M_pad * D * 2)); HIP_TRY(hipMalloc(&ln_out, M_pad * D * 2));
+    HIP_TRY(hipMalloc(&Wu, (int64_t)F * D * 2)); HIP_TRY(hipMalloc(&Wd, (int64_t)F * D * 2));
+    HIP_TRY(hipMalloc(&x, M_pad * D * 4)); HIP_TRY(hipMalloc(&x2, M_pad * D * 4)); HIP_TRY(hipMalloc(&vec, F * 4));
+    HIP_TRY(hipMemset(vec, 0, F * 4)); HIP_TRY(hipMemset(x, 0, M_pad * D * 4)); HIP_TRY(hipMemset(x2, 0, M_pad * D * 4));
+    auto fill = [&](f16* p, int64_t cnt, unsigned seed, float sc) {
+        hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, p, cnt, seed, sc);
+    };
+    fill(h16, M_pad * D, 1u, 1.0f); fill(u16, M_pad * (int64_t)F, 2u, 1.0f); fill(qkv, M_pad * 3 * D, 3u, 1.0f);
+    fill(Wu, (int64_t)F * D, 4u, 0.05f); fill(Wd, (int64_t)F * D, 5u, 0.02f);
+    HIP_TRY(hipDeviceSynchronize());
+    GemmParams up{}; up.A = h16; up.W = Wu; up.M = M; up.M_pad = (int)M_pad; up.N = F; up.K = D; up.bias = vec; up.out_f16 = u16; up.ldo = F;
+    GemmParams dn{}; dn.A = u16; dn.W = Wd; dn.M = M; dn.M_pad = (int)M_pad; dn.N = D; dn.K = F; dn.bias = vec; dn.lambda = vec; dn.out_f32 = x2; dn.ldo = D;
+    hipStream_t st[4]; hipEvent_t e0[4], e1[4];
+    for (int b = 0; b < 4; ++b) { HIP_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking)); HIP_TRY(hipEventCreate(&e0[b])); HIP_TRY(hipEventCreate(&e1[b])); }
+    auto launch = [&](int b) -> int {
+        switch (b) {
+            case 0: return launch_gemm(EPI_GELU, up, st[0]);
+            case 1: return launch_layernorm_f16(x, D, vec, vec, ln_out, M, D, 1e-5f, st[1]);
+            case 2: return launch_attention(qkv, nullptr, ctx, nullptr, 0, n, T, D, 12, st[2]);
+            default: return launch_gemm(EPI_RESID, dn, st[3]);
+        }
+    };
+    for (int b = 0; b < 4; ++b) if (mode & (1 << b)) for (int i = 0; i < 3; ++i) if (launch(b)) return cbas_fail(CBAS_EINVAL, "launch %d failed", b);
+    HIP_TRY(hipDeviceSynchronize());
+    const auto w0 = std::chrono::steady_clock::now();
+    for (int b = 0; b < 4; ++b) if (mode & (1 << b)) HIP_TRY(hipEventRecord(e0[b], st[b]));
+    for (int i = 0; i < iters; ++i)                       // interleaved submission, like two lanes queueing their kernels
+        for (int b = 0; b < 4; ++b) if (mode & (1 << b)) launch(b);
+    for (int b = 0; b < 4; ++b) if (mode & (1 << b)) HIP_TRY(hipEventRecord(e1[b], st[b]));
+    HIP_TRY(hipDeviceSynchronize());
+    ms_out[4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    for (int b = 0; b < 4; ++b) {
+        ms_out[b] = 0.f;
+        if (mode & (1 << b)) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0[b], e1[b])); ms_out[b] = ms / iters; }
+        hipStreamDestroy(st[b]); hipEventDestroy(e0[b]); hipEventDestroy(e1[b]);
+    }
+    hipFree(h16); hipFree(u16); hipFree(qkv); hipFree(ctx); hipFree(ln_out); hipFree(Wu); hipFree(Wd); hipFree(x); hipFree(x2); hipFree(vec);
     return CBAS_OK;
 }
 

@@ -171,6 +171,12 @@ int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes)
 int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
                           unsigned long long* checksum_out);
 
+/* Bring-up: how kernels of two compute lanes share the chip.  Concurrently, each on its own stream, `iters` launches of
+ * bit 0 the up projection (12 864 x 3072 x 768, GELU), bit 1 LayerNorm (12 864 x 768), bit 2 attention (64 x 201 tokens,
+ * 12 heads), bit 3 the down projection (residual epilogue).  ms_out[0..3] = average milliseconds per launch of each
+ * component on its stream, ms_out[4] = wall milliseconds of the whole run (scripts/overlap_kernels.py). */
+int cbas_debug_overlap(int mode, int iters, float* ms_out);
+
 /* Bring-up / tests: the MX-fp8 GEMM of precision 2 in isolation.  A (M x K) and W (N x K) fp32 host matrices are
  * quantised with the library's block quantiser (e4m3 elements, one E8M0 scale per 32 k-elements), multiplied by the
  * fp8 kernel (tile: 0 = the shape's default, 13..16 = a fixed ping-pong tile) and out = A_q W_q^T (M x N fp32) is
