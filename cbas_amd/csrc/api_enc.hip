@@ -1035,6 +1035,9 @@ __global__ void fill_random_f16(f16* p, int64_t n, uint32_t seed, float scale) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     p[i] = (f16)(((float)(x & 0xFFFF) / 32768.0f - 1.0f) * scale);
 }
+__global__ void mask_bytes_kernel(uint32_t* p, int64_t n) {       // clear bit 3 of every byte: no e4m3 NaN codes
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] &= 0x77777777u;
+}
 __global__ void checksum_u16(const uint16_t* p, int64_t n, unsigned long long* out) {
     unsigned long long s = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -1047,8 +1050,11 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
                                      unsigned long long* checksum_out) {
     // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100;
     // tile >= 200: q|k|v epilogue (RoPE tables of 196 patches, 201 tokens per frame, D = N / 3) with tile id = tile - 200
+    // + 500: MX-fp8 operands (random e4m3 bytes, unit scales; the GELU form then writes fp8 + scales): timing only
     const bool want_stamps = tile >= 1000;   // 1000 + tile: also print the block timeline statistics
     tile %= 1000;
+    const bool f8 = tile >= 500;
+    if (f8) tile -= 500;
     const bool qkv = tile >= 200;
     const bool resid = !qkv && tile >= 100;
     if (qkv) tile -= 200;
@@ -1071,6 +1077,17 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)(((int64_t)N * K + 255) / 256)), dim3(256), 0, 0, Wt, (int64_t)N * K, 2u, 0.05f);
     GemmParams p{};
     p.tile = tile; p.A = A; p.W = Wt; p.M = M; p.M_pad = (int)M_pad; p.N = N; p.K = K; p.bias = bias; p.out_f16 = out; p.ldo = N;
+    uint32_t* sc8 = nullptr;
+    if (f8) {                                    // the fp16 buffers reinterpreted as bytes (first half used); NaN codes masked out
+        if (K % 256 || N % 256) return cbas_fail(CBAS_EINVAL, "fp8 GEMM bench needs N, K multiples of 256");
+        hipLaunchKernelGGL(mask_bytes_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t*)A, M_pad * (int64_t)K / 4);
+        hipLaunchKernelGGL(mask_bytes_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t*)Wt, (int64_t)N * K / 4);
+        const int64_t sc_ld = M_pad > N ? M_pad : N;
+        HIP_TRY(hipMalloc(&sc8, (size_t)(K / 128 + N / 128) * sc_ld * 4));
+        HIP_TRY(hipMemset(sc8, 0x7a, (size_t)(K / 128 + N / 128) * sc_ld * 4));     // E8M0 2^-5 per block: products stay finite
+        p.A8 = (const uint8_t*)A; p.W8 = (const uint8_t*)Wt; p.A_sc = sc8; p.W_sc = sc8; p.sc_lda = (int)sc_ld; p.sc_ldw = (int)sc_ld;
+        p.out_f8 = (uint8_t*)out; p.out_sc = sc8 + (size_t)(K / 128) * sc_ld; p.sc_ldo = (int)sc_ld;
+    }
     float* x32 = nullptr;
     if (resid) {
         HIP_TRY(hipMalloc(&x32, M_pad * (int64_t)N * 4));
@@ -1087,8 +1104,8 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
         if (e && (atoi(e) & 4)) p.rope_cos = p.rope_sin = nullptr;       // timing experiment: the epilogue without RoPE
         if (e && (atoi(e) & 8)) p.rope_fac = nullptr;                    // ... and with the global [P][64] table
     }
-    const GemmEpilogue epi = qkv ? EPI_QKV : resid ? EPI_RESID : EPI_GELU;
-    if (epi == EPI_GELU) {                       // experiment builds (-DCBAS_EXP_EPI) read flag bits here; unused otherwise
+    const GemmEpilogue epi = qkv ? EPI_QKV : resid ? EPI_RESID : f8 ? EPI_GELU_F8 : EPI_GELU;
+    if (epi == EPI_GELU || epi == EPI_GELU_F8) { // experiment builds (-DCBAS_EXP_EPI) read flag bits here; unused otherwise
         const char* e = getenv("CBAS_EXP_FLAGS");
         p.n_prefix = e ? atoi(e) : 0;
     }
@@ -1108,13 +1125,13 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     if (want_stamps) {
         const int nblk = GEMM_STAMP_BLOCKS;
         unsigned long long* st = nullptr;
-        HIP_TRY(hipMalloc(&st, (size_t)nblk * 40));
-        HIP_TRY(hipMemset(st, 0, (size_t)nblk * 40));
+        HIP_TRY(hipMalloc(&st, (size_t)nblk * 72));
+        HIP_TRY(hipMemset(st, 0, (size_t)nblk * 72));
         p.stamps = st;
         launch_gemm(epi, p, 0);                  // straight after the timed launches: the clock is the loaded one
         HIP_TRY(hipDeviceSynchronize());
-        std::vector<unsigned long long> hs((size_t)nblk * 5);
-        HIP_TRY(hipMemcpy(hs.data(), st, (size_t)nblk * 40, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> hs((size_t)nblk * 9);
+        HIP_TRY(hipMemcpy(hs.data(), st, (size_t)nblk * 72, hipMemcpyDeviceToHost));
         double pro = 0, loop = 0, epi_c = 0, real = 0; int n = 0;
         for (int b = 0; b < nblk; ++b) {
             if (!hs[4 * b + 3]) continue;
@@ -1124,6 +1141,14 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
         // s_memtime ticks are shader cycles; the K loop's span in s_memrealtime (100 MHz) ticks gives the in-kernel clock
         printf("  stamps (first tile of each workgroup): %d workgroups; avg prologue %.0f, K loop %.0f, epilogue %.0f cycles; "
                "in-kernel clock %.2f GHz\n", n, pro / n, loop / n, epi_c / n, real > 0 ? loop / real * 0.1 : 0.0);
+        double lp = 0, ll = 0, le = 0; int ln = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned long long* o = &hs[(size_t)nblk * 5 + 4 * (size_t)b];
+            if (!o[3]) continue;
+            lp += (double)(o[1] - o[0]); ll += (double)(o[2] - o[1]); le += (double)(o[3] - o[2]); ++ln;
+        }
+        if (ln) printf("  last tile of the %d workgroups that ran more than one: prologue %.0f, K loop %.0f, epilogue %.0f cycles\n",
+                       ln, lp / ln, ll / ln, le / ln);
         fflush(stdout);
         p.stamps = nullptr;
         hipFree(st);
@@ -1131,7 +1156,7 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     hipLaunchKernelGGL(checksum_u16, dim3(1024), dim3(256), 0, 0, (const uint16_t*)out, (int64_t)M * N, cs);
     if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, cs, 8, hipMemcpyDeviceToHost));
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32); if (rope) hipFree(rope);
+    hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32); if (rope) hipFree(rope); if (sc8) hipFree(sc8);
     return CBAS_OK;
 }
 

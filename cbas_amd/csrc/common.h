@@ -30,6 +30,29 @@ static __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// Reductions over the lanes l ^ 16 and l ^ 32 (the four lanes that hold one row of an MFMA accumulator tile) through
+// v_permlane16_swap / v_permlane32_swap (gfx950): plain VALU instructions instead of the LDS round trip of ds_bpermute
+// that __shfl_xor compiles to - these sit in the softmax / amax dependency chains.  The swap returns {own value, partner's
+// value} in a lane-dependent order (scripts/probes/probe_permlane_swap.hip), so only commutative operations may use it;
+// max and a single fp32 add are bit-identical to the shuffle forms.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ float xor16_max(float a) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float xor32_max(float a) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float xor16_add(float a) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+static __device__ __forceinline__ float xor32_add(float a) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Branch-free GELU for the fp16 encoder path, four values at once: erfc by Abramowitz-Stegun 7.1.26 (|abs err| <= 3.5e-7
 // over the whole line, three orders below the fp16 rounding applied to the result).  The epilogue that calls this is
 // VALU-bound (128 values per lane), so the form is chosen by instruction count:

@@ -235,6 +235,7 @@ int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
     if (p.A8) {           // MX-fp8 operands exist only in the ping-pong kernel; small problems take its 128-row tile
         if (p.N % 256) return -1;
         const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+        if (p.tile >= GEMM_TILE_PP_256x256 && p.tile <= GEMM_TILE_PP_AUTO) return launch_gemm_8ph(epi, p, p.tile, stream);   // bring-up
         return launch_gemm_8ph(epi, p, t256 >= 120 ? GEMM_TILE_PP_AUTO : GEMM_TILE_PP_128x256, stream);
     }
     if (epi == EPI_GELU_F8) return -1;

@@ -202,7 +202,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     };
 
     f32x4 acc[TM][4];
-    unsigned long long t_start = 0, t_pro = 0, t_loop = 0, r_pro = 0, r_loop = 0;   // r_*: s_memrealtime (100 MHz)
+    unsigned long long t_start = 0, t_top = 0, t_pro = 0, t_loop = 0, r_pro = 0, r_loop = 0;   // r_*: s_memrealtime (100 MHz)
     if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
     stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3);      // K-tile 0 of the first tile
 
@@ -315,6 +315,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     };
 
     for (int id = first;;) {
+        if (p.stamps) t_top = __builtin_amdgcn_s_memtime();
         asm volatile("" : "+v"(lane));
         set_tile(id);                                     // same values the K-tile 0 staging used; see `lane` above
         set_frag_offsets();
@@ -328,7 +329,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         stage(1, 1, 0); stage(1, 1, 1); stage(1, 1, 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (p.stamps && id == first) { t_pro = __builtin_amdgcn_s_memtime(); r_pro = __builtin_amdgcn_s_memrealtime(); }
+        if (p.stamps) { t_pro = __builtin_amdgcn_s_memtime(); r_pro = __builtin_amdgcn_s_memrealtime(); }
         if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
 
         for (int t = 0; t < nk; t += 2) {
@@ -337,7 +338,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the groups: every wave has now left the loop
 
-        if (p.stamps && id == first) { t_loop = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
+        if (p.stamps) { t_loop = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
         const int erow = row0 + wr * WROWS, ecol = col0 + wc * 64;
         const int next = id + stride;
         const bool has_next = next < n_kind;
@@ -352,6 +353,10 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
             unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
             o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
             p.stamps[(size_t)GEMM_STAMP_BLOCKS * 4 + blockIdx.x] = r_loop - r_pro;     // in-kernel clock = loop ticks / this x 100 MHz
+        }
+        if (p.stamps && id != first && !has_next && tid == 0) {      // the workgroup's last tile (steady state of a persistent run)
+            unsigned long long* o = p.stamps + (size_t)GEMM_STAMP_BLOCKS * 5 + (size_t)blockIdx.x * 4;
+            o[0] = t_top; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
         }
         if (!has_next) break;
         id = next;

@@ -21,7 +21,7 @@ enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2
                 GEMM_TILE_PP_192x256 = 14, GEMM_TILE_PP_160x256 = 15, GEMM_TILE_PP_128x256 = 16,
                 GEMM_TILE_PP_AUTO = 17 };       // planner: uniform tile height, or 256-row tiles + 128-row tail
 
-constexpr int GEMM_STAMP_BLOCKS = 16384;     // GemmParams::stamps: [GEMM_STAMP_BLOCKS][4] s_memtime stamps + [GEMM_STAMP_BLOCKS] loop spans in s_memrealtime ticks
+constexpr int GEMM_STAMP_BLOCKS = 16384;     // GemmParams::stamps: [GEMM_STAMP_BLOCKS][4] s_memtime stamps of a workgroup's first tile + [GEMM_STAMP_BLOCKS] loop spans in s_memrealtime ticks + [GEMM_STAMP_BLOCKS][4] stamps of its last tile
 constexpr int ROPE_LDS_ROWS = 192;            // (nh + nw) rows of 128 bytes the q|k|v kernel holds in LDS (24 KiB)
 struct GemmParams {
     int tile;            // GemmTile (0 = pick by shape)

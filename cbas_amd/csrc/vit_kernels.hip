@@ -231,8 +231,8 @@ __device__ __forceinline__ void attn_store_f8(const f32x4 (&o)[4], float inv, ui
         for (int dt = 2 * b; dt < 2 * b + 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) a = fmaxf(a, fabsf(o[dt][r] * inv));
-        a = fmaxf(a, __shfl_xor(a, 16, 64));
-        a = fmaxf(a, __shfl_xor(a, 32, 64));
+        a = xor16_max(a);
+        a = xor32_max(a);
         sb[b] = mx_scale_byte(a);
     }
     if (!valid) return;
@@ -363,8 +363,8 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
             mx = max3_raw(mx, s[kt][0], s[kt][1]);
             mx = max3_raw(mx, s[kt][2], s[kt][3]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float m2 = mx * 1.4426950408889634f;
         float sum = 0.f;
         f16x8 pf[NG];                                                // P^T packed as the B operand of P.V
@@ -379,8 +379,8 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
             sum += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
             pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor16_add(sum);
+        sum = xor32_add(sum);
 
         // ---- O^T = V^T P^T: V through the hardware-transposing LDS read, 8 reads + 4 MFMAs per group
         f32x4 o[4];
@@ -496,8 +496,8 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
             }
             bm = fmaxf(bm, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
         }
-        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        bm = xor16_max(bm);
+        bm = xor32_max(bm);
         const float m_new = fmaxf(m, bm);                      // finite: block 0 always holds key 0
         const float alpha = __builtin_amdgcn_exp2f((m - m_new) * 1.4426950408889634f);
         const float m2 = m_new * 1.4426950408889634f;
@@ -537,8 +537,8 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
         if (kb + 1 < nkb) store_blk((kb + 1) & 1, kv, vv);
         __syncthreads();
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_add(l);
+    l = xor32_add(l);
     if (out_sc) {
         if (wave_active) attn_store_f8(o, 1.0f / l, reinterpret_cast<uint8_t*>(out_v), out_sc, sc_ld, (size_t)b * T + q, q < nq, D, hd, g);
     } else if (q < nq) {
@@ -639,8 +639,8 @@ __global__ __launch_bounds__(512, 2) void attention_stream2_kernel(const f16* __
                 bm = max3_raw(bm, s[kt][0], s[kt][1]);
                 bm = max3_raw(bm, s[kt][2], s[kt][3]);
             }
-            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            bm = xor16_max(bm);
+            bm = xor32_max(bm);
             const float m_new = fmaxf(m, bm);                    // finite: block 0 always holds key 0
             const float alpha = __builtin_amdgcn_exp2f((m - m_new) * 1.4426950408889634f);
             const float m2 = m_new * 1.4426950408889634f;
@@ -678,8 +678,8 @@ __global__ __launch_bounds__(512, 2) void attention_stream2_kernel(const f16* __
             }
         }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_add(l);
+    l = xor32_add(l);
     if (out_sc) {
         if (wave_active) attn_store_f8(o, 1.0f / l, reinterpret_cast<uint8_t*>(out_v), out_sc, sc_ld, (size_t)b * T + q, q < nq, D, hd, g);
     } else if (q < nq) {

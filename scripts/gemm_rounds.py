@@ -1,6 +1,6 @@
 """Launch time of the ping-pong GEMM against the number of tile rounds (256 CUs): fixed cost vs per-round cost.
 
-    python scripts/gemm_rounds.py [N K eoff]      (eoff 0: GELU epilogue, 100: residual epilogue)
+    python scripts/gemm_rounds.py [N K eoff]      (eoff 0: GELU epilogue, 100: residual, 200: q|k|v; + 500: MX-fp8 operands)
 """
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

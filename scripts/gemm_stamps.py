@@ -14,11 +14,12 @@ tiles = [int(t) for t in sys.argv[1].split(",")]           # usage: gemm_stamps.
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 12864
 shapes = os.environ.get("CBAS_STAMP_SHAPES", "up,qkv,oproj,down").split(",")
+f8 = 500 if os.environ.get("CBAS_STAMP_F8") == "1" else 0           # the MX-fp8 kernels instead
 for name, m, n, k, eoff in [("up (gelu)", M, 3072, 768, 0), ("qkv (rope)", M, 2304, 768, 200), ("oproj", M, 768, 768, 100), ("down", M, 768, 3072, 100)]:
     if name.split()[0] not in shapes:
         continue
     for t in tiles:
         ms, cs = C.c_float(), C.c_ulonglong()
         print(f"{name} tile {t}:", flush=True)
-        rc = fn(m, n, k, 1000 + t + eoff, iters, C.byref(ms), C.byref(cs))
+        rc = fn(m, n, k, 1000 + t + eoff + f8, iters, C.byref(ms), C.byref(cs))
         print(f"   {ms.value*1e3:.1f} us rc={rc}", flush=True)
