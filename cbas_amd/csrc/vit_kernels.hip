@@ -261,16 +261,22 @@ __device__ __forceinline__ void attn_store_f8(const f32x4 (&o)[4], float inv, ui
 // swizzles of the two images are applied on the SOURCE address (the LDS side of the DMA is lane-linear), rows past T
 // re-read row T-1 (finite values: their scores are masked, their probabilities exactly 0).
 template <int NKT, int NV, int SPLIT>
-__global__ __launch_bounds__(SPLIT == 2 ? 256 : 512, (SPLIT == 2 ? (NKT > 14 ? 2 : 3) : (NKT > 14 ? 2 : 4)))
+#ifndef CBAS_ATTN_MIN_WAVES
+#define CBAS_ATTN_MIN_WAVES 4      // waves per SIMD the resident kernel is compiled for (6 = 80 VGPRs = three 7-wave workgroups per CU at T = 201: spills, 24.8 us vs 23.4)
+#endif
+__global__ __launch_bounds__(SPLIT == 2 ? 256 : 512, (SPLIT == 2 ? (NKT > 14 ? 2 : 3) : (NKT > 14 ? 2 : CBAS_ATTN_MIN_WAVES)))
 void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls, void* __restrict__ out_v,
                       uint32_t* __restrict__ out_sc, int sc_ld, int T, int D, int n_heads, int n_pairs) {
     f16* __restrict__ out = reinterpret_cast<f16*>(out_v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWS = NKT * 16;
     constexpr int NQK = NV ? NV : NKT;                 // key tiles that need S = K Q^T
     constexpr int NG = NV ? (NV + 1) / 2 : NKT / 2;    // 32-key groups that need P.V
-    char* Ks = smem;
-    char* Vs = smem + ROWS * 128;
+    // LDS: the V image first, then K, NQK tiles each.  With NV odd the last P.V group reads one V tile more than is
+    // held: that read lands on the first K tile - finite values, multiplied by probabilities that are exactly 0.
+    // (T = 201: 2 x 13 tiles = 52 KiB instead of 2 x 14 = 56, which is what lets three workgroups share a CU.)
+    constexpr int ROWS = NQK * 16;
+    char* Vs = smem;
+    char* Ks = smem + ROWS * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     int pair = blockIdx.x, half = 0;
@@ -302,7 +308,7 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
         qf[1] = *reinterpret_cast<const f16x8*>(qsrc + (size_t)qrow * qld + 32 + g * 8);
     };
     // Q of this wave's first tile is fetched before the K/V staging so its latency hides under it
-    f16x8 qf[2] = {}, qn[2] = {};
+    f16x8 qf[2] = {};
     int qt = qt0 + wave;
     if (qt < nqt) load_q(qt, qf);
 
@@ -333,7 +339,6 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
 
     for (; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + li;
-        if (qt + nwaves < nqt) load_q(qt + nwaves, qn);          // next tile's Q under this tile's math
 
         // ---- S^T = K Q^T, two key tiles (4 fragment reads, 4 MFMAs) per group; the scheduling
         // barriers keep the compiler from hoisting every fragment read (4 VGPRs each) up front
@@ -352,6 +357,7 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
             __builtin_amdgcn_sched_barrier(0);
         }
         // s[kt][r] = S[q][key = kt*16 + 4g + r]   (q already carries the 1/8 scale)
+        if (qt + nwaves < nqt) load_q(qt + nwaves, qf);          // Q is dead from here on: the next tile's rows load under the softmax and P.V
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NQK; ++kt) {
@@ -415,7 +421,6 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
                 *reinterpret_cast<f16x4*>(orow + 16 * dt) = hv;
             }
         }
-        qf[0] = qn[0]; qf[1] = qn[1];
     }
 }
 
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void attention_stream2_kernel(const f16* __
 template <int NKT, int NV, int SPLIT>
 int launch_attention_t(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_sc, int sc_ld, int n, int T, int D, int n_heads,
                        hipStream_t stream) {
-    constexpr int lds = NKT * 16 * 128 * 2;
+    constexpr int lds = (NV ? NV : NKT) * 16 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT, NV, SPLIT>),
