@@ -233,61 +233,70 @@ def train_lstm_model(train_set, test_set, seq_len: int, behaviors: list, cancel_
         m.load_state_dict(trainer.weights())
         return m.to(device).eval()
 
-    best_f1, best_state, best_epoch = -1.0, None, -1
-    epoch_reports, epochs_no_improve = [], 0
     labels_range = list(range(len(behaviors)))
+
+    def score(loader, cancel=None):
+        """(sklearn report dict, confusion matrix) of the current parameters on one loader; ({}, empty) for no data."""
+        model = eval_model()
+        try:
+            actual, predicted = _predict(model, loader, device, cancel)
+        finally:
+            model.close()
+        if not actual:
+            return {}, np.array([])
+        report = classification_report(actual, predicted, target_names=behaviors, output_dict=True, zero_division=0,
+                                       labels=labels_range)
+        return report, confusion_matrix(actual, predicted, labels=labels_range)
+
+    def f1_of(report) -> float:
+        return report.get(optimization_target, {}).get("f1-score", -1.0)
+
+    # selection state: the parameters of the best validation epoch so far, and how long it has been since
+    best = {"f1": -1.0, "weights": None, "epoch": -1}
+    stale_epochs = 0
+    epoch_reports = []
     try:
-        for e in range(epochs):
+        for epoch in range(epochs):
             if cancel_event is not None and cancel_event.is_set():
-                return None, epoch_reports, best_epoch
+                return None, epoch_reports, best["epoch"]
             if progress_callback:
-                progress_callback(f"Training Epoch {e + 1}/{epochs}...")
-            for i, (d, l) in enumerate(train_loader):
+                progress_callback(f"Training Epoch {epoch + 1}/{epochs}...")
+            # one pass over the shuffled windows: forward, loss, backward and Adam all inside cbas_head_train_step
+            n_batches = len(train_loader)
+            for i, (windows, labels) in enumerate(train_loader):
                 if cancel_event is not None and cancel_event.is_set():
                     break
-                if d.numel() == 0:
+                if windows.numel() == 0:
                     continue
-                loss = trainer.step(d.float(), l, want_loss=(i % 50 == 0))
+                loss = trainer.step(windows.float(), labels, want_loss=(i % 50 == 0))
                 if loss is not None:
-                    print(f"[Epoch {e + 1}/{epochs} Batch {i}/{len(train_loader)}] Loss: {loss[0]:.4f}")
-            model = eval_model()
-            train_actuals, train_predictions = _predict(model, train_loader, device)
-            if not train_actuals:
-                model.close()
-                epochs_no_improve += 1
-                if epochs_no_improve >= patience:
+                    print(f"[Epoch {epoch + 1}/{epochs} Batch {i}/{n_batches}] Loss: {loss[0]:.4f}")
+            train_report, train_cm = score(train_loader)
+            if not train_report:                        # nothing could be scored (every sample failed to load)
+                stale_epochs += 1
+                if stale_epochs >= patience:
                     break
                 continue
-            train_report = classification_report(train_actuals, train_predictions, target_names=behaviors, output_dict=True,
-                                                 zero_division=0, labels=labels_range)
-            train_cm = confusion_matrix(train_actuals, train_predictions, labels=labels_range)
-            val_report, val_cm = {}, np.array([])
-            if test_loader:
-                val_actuals, val_predictions = _predict(model, test_loader, device, cancel_event)
-                if val_actuals:
-                    val_report = classification_report(val_actuals, val_predictions, target_names=behaviors, output_dict=True,
-                                                       zero_division=0, labels=labels_range)
-                    val_cm = confusion_matrix(val_actuals, val_predictions, labels=labels_range)
-            model.close()
+            val_report, val_cm = score(test_loader, cancel_event) if test_loader else ({}, np.array([]))
             epoch_reports.append(PerformanceReport(train_report, train_cm, val_report, val_cm))
-            current_val_f1 = val_report.get(optimization_target, {}).get("f1-score", -1.0)
-            current_train_f1 = train_report.get(optimization_target, {}).get("f1-score", -1.0)
-            val_str = f"{current_val_f1:.4f}" if test_loader else "N/A"
+            val_f1 = f1_of(val_report)
+            val_str = f"{val_f1:.4f}" if test_loader else "N/A"
             if progress_callback:
-                progress_callback(f"Epoch {e + 1} Val F1: {val_str}")
-            print(f"--- Epoch {e + 1} | Train F1: {current_train_f1:.4f} | Val F1: {val_str} ({optimization_target}) ---")
-            if current_val_f1 > best_f1:
-                best_f1, best_epoch, best_state = current_val_f1, e, trainer.weights()
-                epochs_no_improve = 0
+                progress_callback(f"Epoch {epoch + 1} Val F1: {val_str}")
+            print(f"--- Epoch {epoch + 1} | Train F1: {f1_of(train_report):.4f} | Val F1: {val_str} ({optimization_target}) ---")
+            if val_f1 > best["f1"]:
+                best.update(f1=val_f1, weights=trainer.weights(), epoch=epoch)
+                stale_epochs = 0
             else:
-                epochs_no_improve += 1
-            if test_loader and epochs_no_improve >= patience:
-                log(f"Early stopping triggered at epoch {e + 1}.")
+                stale_epochs += 1
+            if test_loader and stale_epochs >= patience:
+                log(f"Early stopping triggered at epoch {epoch + 1}.")
                 break
-        if best_state is None and epochs > 0 and not test_loader:
-            best_state, best_epoch = trainer.weights(), epochs - 1
+        if best["weights"] is None and epochs > 0 and not test_loader:      # no validation set: keep the last epoch
+            best.update(weights=trainer.weights(), epoch=epochs - 1)
     finally:
         trainer.close()
+    best_state, best_epoch = best["weights"], best["epoch"]
     if best_state:
         final_model = ClassifierLSTMDeltas(in_features, len(behaviors), seq_len=seq_len, lstm_hidden_size=lstm_hidden_size,
                                            lstm_layers=lstm_layers)
