@@ -488,3 +488,24 @@ def test_rope_table_in_lds_equals_global_table_and_the_oracle(hw):
         assert rel.max() < 1e-3, rel
     finally:
         enc.close()
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (3, 50, 70), (5, 33, 97), (2, 128, 48), (7, 80, 80), (4, 17, 200)])
+def test_tiny_odd_frame_sizes_against_the_oracle(n, h, w):
+    """Frame sizes that are not multiples of the patch (the conv drops the remainder, [tf]:82-89), single-row / single-column
+    patch grids and ragged batch sizes: CLS rows against the CPU restatement of the whole encoder."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.VIT_TINY
+    wts = W.synth_encoder_weights(cfg, 99)
+    fr = synth.noise_frames(1000 + h * w + n, n, h, w)
+    enc = DinoEncoder.from_weights(cfg, wts, "cuda", max_batch=8, max_frame=(h, w))
+    try:
+        c16, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+        got = c32.cpu().numpy().astype(np.float64)
+        assert np.array_equal(c16.cpu().numpy(), c32.cpu().numpy().astype(np.float16))
+    finally:
+        enc.close()
+    ref = PO.encode_frames(fr, wts, cfg, batch=n).astype(np.float64)
+    rel = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert rel.max() < 1e-3, rel
