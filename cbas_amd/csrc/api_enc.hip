@@ -1166,6 +1166,8 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
 // ms_out[b] = average time per launch of component b as seen on its stream, ms_out[4] = wall time of the whole run.
 extern "C" int cbas_debug_overlap(int mode, int iters, float* ms_out) {
     if (iters <= 0 || !ms_out) return cbas_fail(CBAS_EINVAL, "bad arguments");
+    const char* te = getenv("CBAS_OVL_T");                   // tokens per frame of the attention component (default 201)
+    const int Ta = te ? atoi(te) : 201;
     const int n = 64, T = 201, D = 768, F = 3072, M = n * T;
     const int64_t M_pad = round_up(M, 256);
     f16 *h16 = nullptr, *u16 = nullptr, *qkv = nullptr, *ctx = nullptr, *Wu = nullptr, *Wd = nullptr, *ln_out = nullptr;
@@ -1189,7 +1191,7 @@ extern "C" int cbas_debug_overlap(int mode, int iters, float* ms_out) {
         switch (b) {
             case 0: return launch_gemm(EPI_GELU, up, st[0]);
             case 1: return launch_layernorm_f16(x, D, vec, vec, ln_out, M, D, 1e-5f, st[1]);
-            case 2: return launch_attention(qkv, nullptr, ctx, nullptr, 0, n, T, D, 12, st[2]);
+            case 2: return launch_attention(qkv, nullptr, ctx, nullptr, 0, n * T / Ta, Ta, D, 12, st[2]);
             default: return launch_gemm(EPI_RESID, dn, st[3]);
         }
     };
