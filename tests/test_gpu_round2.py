@@ -462,7 +462,7 @@ def test_encode_files_two_ranks_real_kernels(tmp_path):
             assert (sha(r["cls_file"]), sha(r["csv_file"])) == e, r["path"]
 
 
-@pytest.mark.parametrize("hw", [(160, 224), (224, 96), (64, 16)])
+@pytest.mark.parametrize("hw", [(160, 224), (224, 96), (64, 16), (16, 3088)])       # last: 1 + 193 table rows > ROPE_LDS_ROWS
 def test_rope_table_in_lds_equals_global_table_and_the_oracle(hw):
     """The q|k|v GEMM of the ping-pong kernel rotates with the RoPE angles factorised by axis and held in LDS
     (gemm_epilogue.h); the [P][64] table in global memory is the fallback (one patch column, or more than
