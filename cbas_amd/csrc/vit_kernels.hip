@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
 // Rows past T re-read row T-1 (finite; their scores are masked to -inf before the max).
 // ---------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(512, 2) void attention_stream2_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
+__global__ __launch_bounds__(512, KT <= 4 ? 6 : 2) void attention_stream2_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
                                                                    void* __restrict__ out_v, uint32_t* __restrict__ out_sc, int sc_ld,
                                                                    int T, int D, int n_heads) {
     constexpr int KB = KT * 16;                                  // keys per block
@@ -872,7 +872,9 @@ int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_
     if (nkt <= 18) return launch_attention_t<18, 0, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
     // T > 288: K/V no longer fit the LDS -> streaming kernel, 128 queries per workgroup
     const int nqb = q_cls ? 1 : ((T + 15) / 16 + 7) / 8;
-    static const int stream_env = [] { const char* e = getenv("CBAS_ATTN_STREAM"); return e ? atoi(e) : 2; }();   // 1: first form
+    // default: 64-key blocks (KT = 4: 74 VGPRs, 32 KiB of LDS -> three workgroups per CU; 217 us at ViT-L/518 batch 32);
+    // CBAS_ATTN_STREAM=2: 128-key blocks (two workgroups per CU, 235 us); 1: the first form
+    static const int stream_env = [] { const char* e = getenv("CBAS_ATTN_STREAM"); return e ? atoi(e) : 3; }();
     if (stream_env == 2) {
         hipLaunchKernelGGL(attention_stream2_kernel<8>, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
                            n_heads);
