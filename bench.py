@@ -12,12 +12,16 @@ the tail inside the timed region).  Weights are synthetic (seeded, counter-based
 gated and there is no network.  With N > 1 each rank streams its own clip (weak scaling, no data-path
 collective) and the output rows are gathered to rank 0 over RCCL inside the timed region.
 
-Three passes over the same K steps:
-  1. `value`: frames already resident in HBM when the clock starts, results left in HBM (the bench contract);
-  2. `host_path`: SURVEY section 8(d)'s end-to-end form - uint8 RGB in pinned host memory ->
-     cbas_fused_push_u8_host (PCIe H2D on the copy stream) -> encoder -> head -> fp16 CLS rows + fp32
-     probabilities back in host memory; reported beside `value`, never as `value`;
-  3. per-kernel HIP-event timing for `roofline` (one batch in flight).
+Passes over the same K steps:
+  1. `value`: SURVEY section 8(d)'s metric definition - uint8 RGB in pinned host memory -> cbas_fused_push_u8_host
+     (PCIe H2D on the copy stream) -> encoder -> head -> fp16 CLS rows + fp32 probabilities back in host memory
+     (with N > 1: in rank 0's host memory, after the RCCL gather).  PCIe inclusive;
+  2. `hbm_resident`: the same K steps with the frames already in HBM when the clock starts and the results left in
+     HBM (the looser figure; it was `value` until round 2), bit-identical outputs;
+  3. per-kernel HIP-event timing for `roofline` (one batch in flight);
+  4. `files_path` (--files F, default 2 clips per rank): the PRODUCT path - cbas_amd.dist.encode_files on synthetic
+     `.npy` clips: shared clip queue, decode-ahead into page-locked buffers, fused encode + classify, gather to rank 0,
+     `_cls.h5` + `_outputs.csv` written by rank 0's writer threads; wall time from the first clip to the last file.
 `gates` = the correctness gates of section 8(d) evaluated in this very process against the fixtures made from the
 reference (tests/golden): CLS relative error on the golden frames, head label mismatches on golden rows.
 
@@ -120,6 +124,62 @@ def gates(enc, head, model: str, hw: int, precision: int) -> dict:
     return out
 
 
+def files_pass(args, enc, head, rank: int, world: int, device) -> dict:
+    """The product path on files: every rank writes `--files` synthetic `.npy` clips (uint8 (n,H,W,3), what decord hands
+    encode_file), then all ranks drain the whole list with cbas_amd.dist.encode_files - shared clip queue, decode-ahead
+    into page-locked buffers, fused encode + classify, rows gathered to rank 0, `_cls.h5` + `_outputs.csv` written by rank
+    0's writer threads.  One untimed pass (buffers, sessions, communicator), one timed pass, barrier to barrier."""
+    import shutil
+    import tempfile
+    from cbas_amd import pipeline as P
+    names = [f"b{i}" for i in range(BEHAVIORS)]
+    root = args.files_dir
+    if rank == 0 and root is None:
+        root = tempfile.mkdtemp(prefix="cbas_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    if world > 1:
+        box = [root]
+        torch.distributed.broadcast_object_list(box, src=0, device=device if torch.distributed.get_backend() == "nccl" else None)
+        root = box[0]
+    os.makedirs(root, exist_ok=True)
+    n, hw = args.clip_frames, args.hw
+    gen = torch.Generator(device=device)
+    for j in range(args.files):
+        gen.manual_seed(7000 + rank * 100 + j)
+        fr = torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, device=device, generator=gen).cpu().numpy()
+        np.save(os.path.join(root, f"clip_r{rank:02d}_{j:02d}.npy"), fr)
+        del fr
+    cdist.barrier()
+    paths = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith(".npy"))
+    P.set_project_stamp("bench/synthetic-" + args.model)
+    try:
+        def once():
+            cdist.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            recs = cdist.encode_files(paths, enc, head=head, dataset_name="bench", behaviors=names, temperature=1.0)
+            cdist.barrier()
+            return cdist.max_over_ranks(time.perf_counter() - t0, device), recs
+        once()
+        dt, recs = once()
+    finally:
+        P.set_project_stamp(None)
+    out = None
+    if rank == 0:
+        ok = [r for r in recs if r["status"] == "ok" and r["cls_file"] and r["csv_file"]]
+        frames = sum(r["frames"] for r in ok)
+        per_rank = [sum(1 for r in recs if r["rank"] == k) for k in range(world)]
+        out = {"value": round(frames / dt, 2), "unit": "frames/s", "clips": len(paths), "clips_ok": len(ok),
+               "frames_per_clip": n, "seconds": round(dt, 4), "clips_per_rank": per_rank,
+               "bytes_written": int(sum(os.path.getsize(r["cls_file"]) + os.path.getsize(r["csv_file"]) for r in ok)),
+               "what": "cbas_amd.dist.encode_files over synthetic .npy clips (page cache -> page-locked ring -> HBM -> fused "
+                       "encode + classify -> gather to rank 0 -> _cls.h5 + _outputs.csv on rank 0's writer threads); "
+                       "barrier to barrier, second pass"}
+    cdist.barrier()
+    if rank == 0 and args.files_dir is None:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +195,9 @@ def main() -> None:
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-gates", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (compute lanes of the encoder)")
+    ap.add_argument("--files", type=int, default=2, help="clips per rank of the files_path pass (0: skip it)")
+    ap.add_argument("--clip-frames", type=int, default=2048, help="frames per clip of the files_path pass")
+    ap.add_argument("--files-dir", default=None, help="where the synthetic clips go (default: a temp dir under /dev/shm)")
     args = ap.parse_args()
 
     # RCCL ("nccl") on a real multi-GPU node.  CBAS_DIST_BACKEND=gloo rehearses the multi-rank control
@@ -212,28 +275,48 @@ def main() -> None:
         cdist.barrier()
         return cdist.max_over_ranks(time.perf_counter() - t0, device)
 
+    def run_host_gathered(steps: int):
+        """The section 8(d) pass: pinned host frames in; rows in (rank 0's) host memory out.  With N > 1 the other ranks'
+        rows go HBM -> xGMI -> rank 0's HBM -> rank 0's host memory (no host hop on the sending side)."""
+        if world == 1:
+            return run_host(steps)
+        stream.reset()
+        for s in range(steps):
+            o = (s * B) % n_res
+            stream.push_host(clip_host[o:o + B])
+        if rank == 0:
+            c16h, prh = stream.finish_host()
+            g16 = cdist.gather_rows([torch.empty((0, cfg.hidden_size), dtype=torch.float16, device=device)], dst=0)
+            gpr = cdist.gather_rows([torch.empty((0, BEHAVIORS), dtype=torch.float32, device=device)], dst=0)
+            hosted = [(t[0].cpu(), u[0].cpu()) for t, u in zip(g16[1:], gpr[1:])]       # rank 0 now holds every row
+            assert all(t.shape[0] == steps * B for t, _ in hosted)
+            return c16h, prh
+        c16, pr = stream.finish()
+        cdist.gather_rows([c16], dst=0)
+        cdist.gather_rows([pr], dst=0)
+        return None, None
+
     def timed_host():
         cdist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        c16h, prh = run_host(K)
-        if world > 1:
-            gather(torch.from_numpy(c16h).to(device), torch.from_numpy(prh).to(device))
+        c16h, prh = run_host_gathered(K)
         torch.cuda.synchronize(device)
         cdist.barrier()
         return cdist.max_over_ranks(time.perf_counter() - t0, device), c16h, prh
 
-    # pass 1: the timed region proper (EXACTLY K steps, nothing instrumented) -> value
+    # pass 2 of the docstring first (it also serves as extra warm-up): frames resident in HBM, results left there
     dt = timed()
-    # pass 1b: the same K steps from pinned host memory, results back in host memory -> host_path
+    # pass 1: the timed region proper (EXACTLY K steps, nothing instrumented): pinned host memory -> host memory -> value
     dt_host, host_equal = None, None
     if clip_host is not None:
-        run_host(max(Wm, 1))
+        run_host_gathered(max(Wm, 1))
         dt_host, c16h, prh = timed_host()
         c16d, prd = run(K)                        # the two passes must agree bit for bit
         torch.cuda.synchronize(device)
-        host_equal = bool(np.array_equal(c16d.cpu().numpy().view(np.uint16), c16h.view(np.uint16)) and
-                          np.array_equal(prd.cpu().numpy(), prh))
+        if rank == 0:
+            host_equal = bool(np.array_equal(c16d.cpu().numpy().view(np.uint16), c16h.view(np.uint16)) and
+                              np.array_equal(prd.cpu().numpy(), prh))
     # pass 2: the same K steps again with every kernel launch bracketed by HIP events on the launch
     # stream -> per-kernel durations for the roofline (the events cost a few % of throughput, which
     # is why they are kept out of pass 1; both wall times are reported)
@@ -249,20 +332,30 @@ def main() -> None:
         enc.profile(False)
         enc.set_lanes(args.lanes)
 
+    files = None
+    if args.files > 0:
+        files = files_pass(args, enc, head, rank, world, device)
+
     if rank != 0:
         return
     frames_total = K * B * world
-    value = frames_total / dt
+    hbm_value = frames_total / dt
+    value = frames_total / dt_host if dt_host is not None else hbm_value
+    dt_value = dt_host if dt_host is not None else dt
     flops_frame = cfg.flops_per_frame(args.hw, args.hw) + hcfg.flops_per_frame_naive()
 
     out = {
         "metric": METRIC, "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt_value / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8" if args.precision == 2 else "f16", "data": "synthetic",
         "config": {"workload": f"DINOv3 ViT-{args.model[3:].upper()} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
                                f"batch={B}, chunked encode + BiLSTM head (C={BEHAVIORS}, seq_len={SEQ_LEN})",
-                   "input": "uint8 RGB frames resident in HBM before the clock starts; CLS rows and probabilities left in HBM "
-                            "(host-memory-to-host-memory figure: host_path)",
+                   "input": ("uint8 RGB (n,H,W,3) in pinned host memory -> cbas_fused_push_u8_host (H2D on the copy stream, green "
+                             "picked on the device) -> encoder -> head -> fp16 CLS rows + fp32 probabilities in host memory"
+                             + (" of rank 0 (RCCL gather inside the timed region)" if world > 1 else "") +
+                             ": SURVEY section 8(d)'s metric definition, PCIe inclusive (HBM-resident figure: hbm_resident)")
+                            if dt_host is not None else
+                            "uint8 RGB frames resident in HBM before the clock starts; results left in HBM (--no-host-path)",
                    "batch": B, "batches_in_flight": args.lanes, "frames_per_gpu": K * B, "frame": [args.hw, args.hw], "parallelism": f"clip-per-gpu x{world}",
                    "weights": "synthetic (seeded counter-based generator)", "operands": ("MX-fp8 (e4m3 + E8M0 block-32 scales) MFMA for qkv/o_proj/up/down, fp16 attention/patch/CLS tail, "
                                 "fp32 accumulate/residual; head fp32") if args.precision == 2 else
@@ -272,12 +365,13 @@ def main() -> None:
         "end_to_end_tflops": round(value * flops_frame / 1e12, 2),
     }
     if dt_host is not None:
-        out["host_path"] = {
-            "value": round(frames_total / dt_host, 2), "unit": "frames/s", "ms_per_step": round(dt_host / K * 1e3, 4),
-            "what": "uint8 RGB (n,H,W,3) in pinned host memory -> cbas_fused_push_u8_host (H2D on the copy stream, green "
-                    "picked on the device) -> encoder -> head -> fp16 CLS rows + fp32 probabilities in host memory "
-                    "(SURVEY section 8(d) metric definition); same K steps, PCIe inclusive",
-            "h2d_bytes_per_frame": args.hw * args.hw * 3, "bit_identical_to_hbm_resident_pass": host_equal}
+        out["hbm_resident"] = {
+            "value": round(hbm_value, 2), "unit": "frames/s", "ms_per_step": round(dt / K * 1e3, 4),
+            "what": "the same K steps with the uint8 frames already in HBM when the clock starts and the CLS rows / "
+                    "probabilities left in HBM (gathered to rank 0's HBM with N > 1); no PCIe traffic in the timed region",
+            "h2d_bytes_per_frame_of_value": args.hw * args.hw * 3, "bit_identical_to_value_pass": host_equal}
+    if files is not None:
+        out["files_path"] = files
     if not args.no_gates:
         out["gates"] = gates(enc, head, args.model, args.hw, args.precision)
     if prof:

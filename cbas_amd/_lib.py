@@ -66,6 +66,7 @@ SIGNATURES = {
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int, c_int]),
     "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_enc_debug_option": (c_int, [c_void_p, C.c_char_p, c_int]),
     "cbas_debug_overlap": (c_int, [c_int, c_int, C.POINTER(c_float)]),
     "cbas_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float),
                                       C.POINTER(C.c_ulonglong)]),
@@ -81,19 +82,23 @@ SIGNATURES = {
     "cbas_head_infer_f16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "cbas_head_infer_f16_range": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_void_p,
                                           c_void_p]),
+    "cbas_head_infer_f32_range": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_void_p,
+                                          c_void_p]),
     "cbas_head_train_create": (c_int, [C.POINTER(HeadConfigC), C.POINTER(TrainConfigC), c_void_p, c_int64, c_void_p, c_int,
                                        C.POINTER(c_void_p)]),
     "cbas_head_train_destroy": (None, [c_void_p]),
     "cbas_head_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "cbas_head_train_read": (c_int, [c_void_p, c_int32, c_void_p, c_int64]),
     "cbas_head_train_last_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_int32]),
+    "cbas_csv_format_f32": (c_int64, [c_void_p, c_int64, c_int32, c_void_p, c_int64]),
+    "cbas_csv_write_f32": (c_int, [C.c_char_p, C.c_char_p, c_void_p, c_int64, c_int32, c_int32]),
     "cbas_last_error": (C.c_char_p, []),
     "cbas_abi_version": (c_int, []),
     "cbas_device_info": (c_int, [c_int, C.c_char_p, c_int, C.POINTER(c_int32), C.POINTER(c_int64)]),
 }
 
 ENC_SLOTS = 3
-EXPECTED_ABI = 6          # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
+EXPECTED_ABI = 7          # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
 PROF_CATS = ["patch_gemm", "layernorm", "qkv_gemm", "attention", "oproj_gemm", "up_gemm", "down_gemm", "other"]
 
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libcbas_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["gemm_f16.hip", "gemm_f16_8ph.hip", "gemm_f16_skinny.hip", "gemm_f32.hip", "vit_kernels.hip", "head_kernels.hip", "head_train_kernels.hip",
-           "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip"]
+           "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip", "host_text.cpp"]
 ARCH = "gfx950"
 
 
@@ -44,7 +44,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         srcp = os.path.join(CSRC, src)
         headers = [os.path.join(CSRC, hname) for hname in os.listdir(CSRC) if hname.endswith(".h")]

@@ -91,6 +91,7 @@ struct cbas_enc {
     // cls16 = [q | ctx | LN2 | (pad)] x [max_batch][D] fp16, then GELU(up) [max_batch][F]
     f16* cls16 = nullptr;
     bool prune_last = true;
+    bool rope_in_lds = true;           // cbas_enc_debug_option("rope_lds"): q|k|v epilogue reads the by-axis RoPE table from LDS
     int last_rows = 0;
     hipStream_t compute = nullptr, copy = nullptr;
     Slot slots[CBAS_ENC_SLOTS];
@@ -272,7 +273,7 @@ int ensure_rope(cbas_enc* h, int nh, int nw) {
 void set_rope(const cbas_enc* h, GemmParams& p) {
     if (!h->cfg.use_rope) return;
     p.rope_cos = h->rope_cos; p.rope_sin = h->rope_sin;
-    p.rope_fac = h->rope_fac; p.rope_nh = h->rope_nh; p.rope_nw = h->rope_nw;
+    p.rope_fac = h->rope_in_lds ? h->rope_fac : nullptr; p.rope_nh = h->rope_nh; p.rope_nw = h->rope_nw;
     p.rope_magic = (unsigned)((1ull << 32) / (unsigned)h->rope_nw) + 1u;
 }
 
@@ -687,7 +688,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->u16, 0, h->rows_cap * F * sizeof(f16), st));
-    // second compute lane (see cbas_enc::Lane); CBAS_LANES=1 keeps a single lane
+    // second compute lane (see cbas_enc::Lane); CBAS_LANES=1 (read here, once per handle) keeps a single lane
     {
         const char* e = getenv("CBAS_LANES");
         h->n_lanes = (e && atoi(e) == 1) ? 1 : 2;
@@ -976,6 +977,12 @@ extern "C" int cbas_enc_set_prune_last_layer(cbas_enc* h, int enable) {
     return CBAS_OK;
 }
 
+extern "C" int cbas_enc_debug_option(cbas_enc* h, const char* name, int value) {
+    if (!h || !name) return cbas_fail(CBAS_EINVAL, "null argument");
+    if (!strcmp(name, "rope_lds")) { h->rope_in_lds = value != 0; return CBAS_OK; }
+    return cbas_fail(CBAS_EINVAL, "unknown debug option '%s'", name);
+}
+
 extern "C" int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
     if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
@@ -1100,15 +1107,8 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
         HIP_TRY(hipMemset(rope, 0, 2 * 196 * 64 * 4));
         p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3; p.tokens_per_frame = 201; p.n_prefix = 5;
         p.rope_fac = rope; p.rope_nh = 14; p.rope_nw = 14; p.rope_magic = (unsigned)((1ull << 32) / 14u) + 1u;   // zeros: timing only
-        const char* e = getenv("CBAS_EXP_FLAGS");
-        if (e && (atoi(e) & 4)) p.rope_cos = p.rope_sin = nullptr;       // timing experiment: the epilogue without RoPE
-        if (e && (atoi(e) & 8)) p.rope_fac = nullptr;                    // ... and with the global [P][64] table
     }
     const GemmEpilogue epi = qkv ? EPI_QKV : resid ? EPI_RESID : f8 ? EPI_GELU_F8 : EPI_GELU;
-    if (epi == EPI_GELU || epi == EPI_GELU_F8) { // experiment builds (-DCBAS_EXP_EPI) read flag bits here; unused otherwise
-        const char* e = getenv("CBAS_EXP_FLAGS");
-        p.n_prefix = e ? atoi(e) : 0;
-    }
     int rc = launch_gemm(epi, p, 0);
     if (rc) return cbas_fail(CBAS_EINVAL, "launch_gemm failed for tile %d (rc=%d)", tile, rc);
     HIP_TRY(hipDeviceSynchronize());

@@ -45,6 +45,7 @@ int drain(cbas_fused* f) {
 }
 
 int classify(cbas_fused* f, int64_t count, int64_t n_rows) {
+    if (!f->head) { f->classified += count; return CBAS_OK; }       // encode-only session
     int rc = cbas_head_infer_f16_range(f->head, f->cls16, n_rows, f->classified, count, f->temperature,
                                        f->probs + f->classified * f->C, nullptr, f->st);
     if (rc) return rc;
@@ -90,14 +91,18 @@ int push(cbas_fused* f, const uint8_t* frames, bool host, int n, int height, int
 
 extern "C" int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacity_frames, float temperature,
                                  int64_t classify_every, cbas_fused** out) {
-    if (!enc || !head || !out) return cbas_fail(CBAS_EINVAL, "null argument");
+    if (!enc || !out) return cbas_fail(CBAS_EINVAL, "null argument");
     *out = nullptr;
     cbas_enc_config ec;
-    cbas_head_config hc;
+    cbas_head_config hc{};
     int rc = cbas_enc_get_config(enc, &ec);
     if (rc) return rc;
-    rc = cbas_head_get_config(head, &hc);
-    if (rc) return rc;
+    if (head) {
+        rc = cbas_head_get_config(head, &hc);
+        if (rc) return rc;
+    } else {                                   // encode-only session: the chunk loop of encode_file with the rows kept in HBM
+        hc.in_features = ec.hidden_size; hc.out_features = 0; hc.seq_len = 1;
+    }
     if (hc.in_features != ec.hidden_size)
         return cbas_fail(CBAS_EINVAL, "head expects %d features, the encoder emits %d", hc.in_features, ec.hidden_size);
     if (capacity_frames <= 0) return cbas_fail(CBAS_EINVAL, "capacity_frames=%lld", (long long)capacity_frames);
@@ -109,7 +114,7 @@ extern "C" int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacit
     f->classify_every = classify_every > 0 ? classify_every : 1024;
     hipError_t e = hipGetDevice(&f->device);
     if (e == hipSuccess) e = hipMalloc(&f->cls16, (size_t)capacity_frames * f->D * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMalloc(&f->probs, (size_t)capacity_frames * f->C * sizeof(float));
+    if (e == hipSuccess && f->C > 0) e = hipMalloc(&f->probs, (size_t)capacity_frames * f->C * sizeof(float));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
     if (e != hipSuccess) {
         cbas_fail(e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP, "cbas_fused_create: %s", hipGetErrorString(e));
@@ -162,7 +167,7 @@ extern "C" int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* p
     }
     if (cls_f16_host)
         HIP_TRY(hipMemcpyAsync(cls_f16_host, f->cls16, (size_t)f->encoded * f->D * 2, hipMemcpyDeviceToHost, f->st));
-    if (probs_host)
+    if (probs_host && f->C > 0)
         HIP_TRY(hipMemcpyAsync(probs_host, f->probs, (size_t)f->encoded * f->C * 4, hipMemcpyDeviceToHost, f->st));
     if (cls_f16_dev) *cls_f16_dev = f->cls16;
     if (probs_dev) *probs_dev = f->probs;

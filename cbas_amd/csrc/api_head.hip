@@ -9,7 +9,7 @@
 #include "kernels.h"
 
 namespace {
-constexpr int64_t WCHUNK = 4096;     // windows per pass (bounds the workspace at ~1 GB for h=64)
+constexpr int64_t WCHUNK = 4096;     // most windows per pass (bounds the workspace at ~1 GB for T = 31, h = 64)
 }
 
 struct cbas_head {
@@ -23,9 +23,13 @@ struct cbas_head {
     const float *w_ih[4], *b_gate[4], *w_hh[4];       // per stacked LSTM layer: [8h][in], [8h], [2][4h][h]
     float b_att, gate_sigmoid, att_temp;
     // workspaces
+    // workspaces: sized by the largest pass seen so far (grow-only; a 4096-window pass at T = 31, h = 64 takes ~1 GB,
+    // a 64-window call a few MB), allocated by ensure_workspace on the first call that needs them
     float *rows32 = nullptr, *proj = nullptr, *aug = nullptr, *xl = nullptr, *gin = nullptr, *hout = nullptr,
           *lin_logits = nullptr, *hfull = nullptr;     // hfull: [w][T][2h], inner-layer outputs of a stacked LSTM
-    int64_t proj_rows_cap = 0;
+    int64_t win_cap = 0;             // windows per pass the per-window buffers hold
+    int64_t proj_rows_cap = 0;       // rows of `proj` (explicit windows: w*T; sliding: w + T)
+    int64_t rows32_cap = 0;          // rows of `rows32` (sliding mode with half-precision input only)
 };
 
 namespace {
@@ -62,6 +66,49 @@ int run_chunk(cbas_head* h, int64_t nw, int sliding, int64_t w0, int64_t r0, int
     }
     LAUNCH_TRY(launch_head_pool(h->hout, h->lin_logits, d, h->w_att, h->b_att, h->att_temp, h->w_lin2, h->b_lin2,
                                 h->gate_sigmoid, temperature, nw, probs, logits, latent, st));
+    return CBAS_OK;
+}
+
+// Make the workspace hold one pass of `nw` windows (sliding = rows shared between windows: nw + T projected rows;
+// explicit windows: nw * T).  Buffers only grow; growing synchronises the device first (earlier passes may still read
+// the old buffers), which happens at most a few times in a handle's life.
+int ensure_workspace(cbas_head* h, int64_t nw, bool sliding) {
+    const HeadDims& d = h->d;
+    const int64_t T = d.T, rows = sliding ? nw + T : nw * T;
+    const bool grow_w = nw > h->win_cap, grow_p = rows > h->proj_rows_cap, grow_r = sliding && rows > h->rows32_cap;
+    if (!grow_w && !grow_p && !grow_r) return CBAS_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    auto regrow = [](float** p, int64_t elems) -> hipError_t {
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+        return hipMalloc(p, (size_t)elems * sizeof(float));
+    };
+    if (grow_w) {
+        int64_t w = 2 * h->win_cap < WCHUNK ? 2 * h->win_cap : WCHUNK;      // geometric: few regrowths
+        if (w < nw) w = nw;
+        if (w < 256) w = 256;
+        h->win_cap = 0;
+        HIP_TRY(regrow(&h->aug, w * T * d.NS * d.Bn));
+        HIP_TRY(regrow(&h->xl, w * T * d.L0));
+        HIP_TRY(regrow(&h->gin, w * T * 8 * d.h));
+        HIP_TRY(regrow(&h->hout, w * (d.hi - d.lo) * 2 * d.h));
+        HIP_TRY(regrow(&h->lin_logits, w * d.C));
+        if (h->n_layers > 1) HIP_TRY(regrow(&h->hfull, w * T * 2 * d.h));
+        h->win_cap = w;
+    }
+    if (grow_p) {
+        int64_t r = 2 * h->proj_rows_cap < WCHUNK * T ? 2 * h->proj_rows_cap : WCHUNK * T;
+        if (r < rows) r = rows;
+        h->proj_rows_cap = 0;
+        HIP_TRY(regrow(&h->proj, r * d.NPROJ));
+        h->proj_rows_cap = r;
+    }
+    if (grow_r) {
+        int64_t r = 2 * h->rows32_cap < WCHUNK + T ? 2 * h->rows32_cap : WCHUNK + T;
+        if (r < rows) r = rows;
+        h->rows32_cap = 0;
+        HIP_TRY(regrow(&h->rows32, r * d.I));
+        h->rows32_cap = r;
+    }
     return CBAS_OK;
 }
 
@@ -203,15 +250,7 @@ extern "C" int cbas_head_create(const cbas_head_config* cfg, const float* weight
     for (int l = 0; l < NL; ++l) { h->w_ih[l] = h->wbuf + o_wih[l]; h->b_gate[l] = h->wbuf + o_bgate[l]; h->w_hh[l] = h->wbuf + o_whh[l]; }
     h->w_att = h->wbuf + o_watt; h->w_lin2 = h->wbuf + o_wlin2; h->b_lin2 = h->wbuf + o_blin2;
 
-    h->proj_rows_cap = WCHUNK * T;       // explicit-window mode needs WCHUNK*T rows, sliding WCHUNK+T
-    CREATE_TRY(hipMalloc(&h->rows32, (WCHUNK + T) * I * sizeof(float)));   // sliding mode: chunk + halo rows
-    CREATE_TRY(hipMalloc(&h->proj, h->proj_rows_cap * d.NPROJ * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->aug, WCHUNK * T * NS * Bn * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->xl, WCHUNK * T * L0 * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->gin, WCHUNK * T * 8 * hh * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->hout, WCHUNK * (hi - lo) * 2 * hh * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->lin_logits, WCHUNK * C * sizeof(float)));
-    if (NL > 1) CREATE_TRY(hipMalloc(&h->hfull, WCHUNK * T * 2 * hh * sizeof(float)));
+    // activations are allocated on demand (ensure_workspace): nothing here
 #undef CREATE_TRY
     *out = h;
     return CBAS_OK;
@@ -226,7 +265,9 @@ extern "C" int cbas_head_forward_windows(cbas_head* h, const float* x_dev, int64
     const HeadDims& d = h->d;
     for (int64_t w0 = 0; w0 < n_windows; w0 += WCHUNK) {
         const int64_t nw = n_windows - w0 < WCHUNK ? n_windows - w0 : WCHUNK;
-        int rc = project(h, x_dev + w0 * d.T * d.I, nw * d.T, st);
+        int rc = ensure_workspace(h, nw, false);
+        if (rc) return rc;
+        rc = project(h, x_dev + w0 * d.T * d.I, nw * d.T, st);
         if (rc) return rc;
         rc = run_chunk(h, nw, 0, 0, 0, 0, 1.0f, nullptr, logits_dev ? logits_dev + w0 * d.C : nullptr,
                        latent_dev ? latent_dev + w0 * 2 * d.h : nullptr, st);
@@ -235,11 +276,12 @@ extern "C" int cbas_head_forward_windows(cbas_head* h, const float* x_dev, int64
     return CBAS_OK;
 }
 
-extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames,
-                                         int64_t first, int64_t count, float temperature, float* probs_dev,
-                                         float* logits_dev, void* stream) {
+// rows: the clip's CLS rows as IEEE half (what _cls.h5 holds) or float32 (a foreign `cls` dataset, which the reference
+// reads with .float(): backend/cbas.py:507-508)
+static int infer_range(cbas_head* h, const void* cls_dev, bool half_rows, int64_t n_frames, int64_t first, int64_t count,
+                       float temperature, float* probs_dev, float* logits_dev, void* stream) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null head handle");
-    if (!cls_f16_dev || n_frames <= 0) return cbas_fail(CBAS_EINVAL, "cls_f16_dev NULL or n_frames <= 0");
+    if (!cls_dev || n_frames <= 0) return cbas_fail(CBAS_EINVAL, "cls rows NULL or n_frames <= 0");
     if (first < 0 || count <= 0 || first + count > n_frames)
         return cbas_fail(CBAS_EINVAL, "range [%lld, %lld) outside the clip of %lld frames", (long long)first,
                          (long long)(first + count), (long long)n_frames);
@@ -254,8 +296,14 @@ extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_d
         const int64_t r0 = w0 - half > 0 ? w0 - half : 0;
         const int64_t r1 = w0 + nw + half < n_frames ? w0 + nw + half : n_frames;
         const int64_t nr = r1 - r0;
-        LAUNCH_TRY(launch_f16_to_f32((const f16*)cls_f16_dev + r0 * d.I, h->rows32, nr * d.I, st));
-        int rc = project(h, h->rows32, nr, st);
+        int rc = ensure_workspace(h, nw, true);
+        if (rc) return rc;
+        const float* rows32 = (const float*)cls_dev + r0 * d.I;
+        if (half_rows) {
+            LAUNCH_TRY(launch_f16_to_f32((const f16*)cls_dev + r0 * d.I, h->rows32, nr * d.I, st));
+            rows32 = h->rows32;
+        }
+        rc = project(h, rows32, nr, st);
         if (rc) return rc;
         const int64_t o = w0 - first;
         rc = run_chunk(h, nw, 1, w0, r0, n_frames, temperature, probs_dev ? probs_dev + o * d.C : nullptr,
@@ -263,6 +311,18 @@ extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_d
         if (rc) return rc;
     }
     return CBAS_OK;
+}
+
+extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames,
+                                         int64_t first, int64_t count, float temperature, float* probs_dev,
+                                         float* logits_dev, void* stream) {
+    return infer_range(h, cls_f16_dev, true, n_frames, first, count, temperature, probs_dev, logits_dev, stream);
+}
+
+extern "C" int cbas_head_infer_f32_range(cbas_head* h, const float* cls_f32_dev, int64_t n_frames,
+                                         int64_t first, int64_t count, float temperature, float* probs_dev,
+                                         float* logits_dev, void* stream) {
+    return infer_range(h, cls_f32_dev, false, n_frames, first, count, temperature, probs_dev, logits_dev, stream);
 }
 
 extern "C" int cbas_head_infer_f16(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames, float temperature,

@@ -172,17 +172,11 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 w = acc[i][j] + bv[j];
-#ifdef CBAS_EXP_EPI
-                    if (p.n_prefix & 1) { v[j] = w; continue; }
-#endif
                     v[j] = gelu_fast4(w);
                 }
                 int sb[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-#ifdef CBAS_EXP_EPI
-                    if (p.n_prefix & 4) { sb[b] = 127; continue; }
-#endif
                     float a = 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a = fmaxf(a, fmaxf(fabsf(v[2 * b][e]), fabsf(v[2 * b + 1][e])));
@@ -208,9 +202,6 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const int r = it * 16 + (lane >> 2), c = lane & 3;      // 16 rows x 64 bytes per wave store
                 const uint4 q = *reinterpret_cast<const uint4*>(scratch + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
                 const int m = row_base + half * 64 + r;
-#ifdef CBAS_EXP_EPI
-                if ((p.n_prefix & 2) && m >= 0) continue;
-#endif
                 if (m < p.M) *reinterpret_cast<uint4*>(p.out_f8 + (size_t)m * p.ldo + head_col0 + c * 16) = q;
             }
             asm volatile("" ::: "memory");
@@ -290,9 +281,6 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                         for (int j = 0; j < 4; ++j) v[j] = v[j] * qs;
                     }
                 } else {
-#ifdef CBAS_EXP_EPI
-                    if (!(p.n_prefix & 1))
-#endif
                     {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = gelu_fast4(v[j]);
@@ -314,9 +302,6 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const f16x8 hv = *reinterpret_cast<const f16x8*>(sc + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = row_base + half * (PS * 16) + r;
                 {
-#ifdef CBAS_EXP_EPI
-                if (EPI == EPI_GELU && (p.n_prefix & 2) && m >= 0) continue;
-#endif
                 if (m < p.M) __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldo + head_col0 + c * 8));
                 }
             }

@@ -177,11 +177,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(Arsrc, LDS_PTR(base + a_lds[h][s]), 16, a_src[h][s], kt * 128, 0, 0);
-#ifdef CBAS_EXP_NO_SCALE_DMA
-            if (false)
-#else
             if (F8 && h == 1)        // rides with A-sub1: retired by the same counted vmcnt, two barriers before its first read
-#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(Srsrc, LDS_PTR(sc_lds + buf * 2048 + sc_dst), 4, sc_src, kt * sc_step, 0, 0);
         } else {
 #pragma unroll
@@ -257,15 +253,11 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         if constexpr (F8) {
             const i32x4 lo = *reinterpret_cast<const i32x4*>(buf + off0), hi = *reinterpret_cast<const i32x4*>(buf + off1);
             f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#ifdef CBAS_EXP_NO_SCALE_READ
-            f.sc = 127;
-#else
             // The scale byte is read by an asm ds_read_u8: as a C++ byte load hipcc masks it (v_and 0xff) in front of the
             // phase barrier, which puts an lgkmcnt wait ladder - the whole LDS latency of the phase's fragment reads - before
             // every barrier (16 % of the K loop).  Hidden from the compiler the value is only consumed by the MFMAs, behind the
             // explicit lgkmcnt(0) + sched_barrier at the top of mfma_quadrant (the form cdna_hip_programming.md 5.7 (iii) asks for).
             asm volatile("ds_read_u8 %0, %1" : "=v"(f.sc) : "v"((unsigned)(uintptr_t)LDS_PTR(scb + sc_off)));
-#endif
         } else {
             f.h[0] = read_frag8(buf, off0);
             f.h[1] = read_frag8(buf, off1);
@@ -527,10 +519,8 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
 
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p_in, int tile, hipStream_t stream) {
     GemmParams p = p_in;
-    if (p.rope_fac) {                                   // the LDS copy of the RoPE table, or the global [P][64] table
-        const char* e = getenv("CBAS_ROPE_LDS");        // read per launch: tests switch it to compare the two forms
-        if ((e && e[0] == '0') || !p.rope_cos || p.rope_nw <= 1 || p.rope_nh + p.rope_nw > ROPE_LDS_ROWS) p.rope_fac = nullptr;
-    }
+    // the LDS copy of the RoPE table, or the global [P][64] table (the caller passes rope_fac = nullptr to force the latter)
+    if (p.rope_fac && (!p.rope_cos || p.rope_nw <= 1 || p.rope_nh + p.rope_nw > ROPE_LDS_ROWS)) p.rope_fac = nullptr;
     // 32-bit byte offsets into A / W; K-tiles are consumed in pairs
     if (p.W_lo || p.N % 256 || (long long)p.M_pad * p.lda >= (1ll << 31) || (long long)p.N * p.K >= (1ll << 31)) return -1;
     if (p.A8) {                                        // MX-fp8 operands: 128-element K-tiles

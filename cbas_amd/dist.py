@@ -9,6 +9,10 @@ every peer uses its own xGMI link to rank 0 and no rank receives rows it does no
 (``backend="nccl"``); the CPU tests use ``gloo``.
 
 ``encode_files`` is the product entry point: what the reference's queue does for a list of videos, on N GPUs.
+
+Status of the transports: the gloo path runs in the CPU test-suite (world 2, 3, 4) and with two gloo ranks sharing one
+GPU on the real kernels; the RCCL path has not run on a multi-GPU node yet (none was available to the builder) - it is
+the same code with device tensors, kept to grouped point-to-point calls on the world communicator.
 """
 from __future__ import annotations
 
@@ -33,7 +37,12 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            # more ranks than GPUs cannot work on RCCL (one communicator rank per device): say so here, not in a hang
+            ndev = torch.cuda.device_count()
+            if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > max(1, ndev):
+                raise RuntimeError(f"{world} ranks for {ndev} GPU(s): the RCCL backend needs one GPU per rank "
+                                   "(use CBAS_DIST_BACKEND=gloo to rehearse with ranks sharing a GPU)")
+            torch.cuda.set_device(local % max(1, ndev))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -110,84 +119,256 @@ def gather_rows(local: Sequence[torch.Tensor], dst: int = 0) -> Optional[List[Li
     return out
 
 
+class _ClipQueue:
+    """The shared work queue: ``next()`` hands out each clip index exactly once across all ranks (the reference's
+    ``gui_state.encode_tasks`` list popped under ``encode_lock``, backend/workthreads.py:284-290, made node-wide).  It is a
+    counter in the process group's key-value store, so a rank that is given a long clip simply takes fewer of them; no
+    collective is involved and no rank waits for another."""
+
+    def __init__(self, n: int, store, prefix: str):
+        self.n, self._store, self._key, self._local = int(n), store, prefix + "next", 0
+
+    def next(self) -> Optional[int]:
+        if self._store is None:
+            i, self._local = self._local, self._local + 1
+        else:
+            i = int(self._store.add(self._key, 1)) - 1
+        return i if i < self.n else None
+
+
+class _OutputWriter:
+    """Rank 0's file writers, off the encode loop's critical path: ``_cls.h5`` files on ONE thread (libhdf5 is not
+    thread-safe), ``_outputs.csv`` files on a small pool (the native formatter releases the GIL).  ``submit`` only
+    queues; records are completed by the threads; ``close`` waits for everything."""
+
+    def __init__(self, records: List[dict], dataset_name, behaviors, attrs: dict, csv_threads: int = 2, max_pending: int = 16):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self._records, self._name, self._behaviors, self._attrs = records, dataset_name, behaviors, attrs
+        self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
+        self._csv = ThreadPoolExecutor(max_workers=max(1, csv_threads), thread_name_prefix="cbas-csv")
+        self._futs: list = []
+        self._t = threading.Thread(target=self._h5_loop, name="cbas-h5-writer", daemon=True)
+        self._t.start()
+
+    def submit(self, clip: int, rows, probs) -> None:
+        from . import pipeline as P
+        rec = self._records[clip]
+        rec["frames"] = int(rows.shape[0])
+        if probs is not None and self._name is not None:
+            csv = os.path.splitext(rec["path"])[0] + f"_{self._name}_outputs.csv"
+            self._futs.append(self._csv.submit(self._write_csv, rec, csv, probs, P))
+        self._q.put((rec, rows))                    # blocks when max_pending clips are waiting: back-pressure
+
+    @staticmethod
+    def _fail(rec, what, e):
+        print(f"ERROR writing {what} of {rec['path']}: {e}")
+        rec["status"] = "failed"
+
+    def _write_csv(self, rec, csv, probs, P):
+        try:
+            P.write_probs_csv(csv, probs, list(self._behaviors))
+            rec["csv_file"] = csv
+        except Exception as e:  # noqa: BLE001
+            self._fail(rec, "the probabilities", e)
+
+    def _h5_loop(self):
+        from . import pipeline as P
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            rec, rows = item
+            try:
+                rec["cls_file"] = P.write_cls_file(rec["path"], rows, self._attrs)
+                print(f"Successfully encoded {os.path.basename(rec['path'])} to {os.path.basename(rec['cls_file'])}")
+            except Exception as e:  # noqa: BLE001
+                self._fail(rec, "the CLS rows", e)
+
+    def close(self) -> None:
+        self._q.put(None)
+        self._t.join()
+        for f in self._futs:
+            f.result()
+        self._csv.shutdown()
+        for rec in self._records:                   # a clip whose CSV or rows failed to be written has no output at all
+            if rec["status"] == "failed":
+                rec["cls_file"] = rec["csv_file"] = None
+
+
+_ef_calls = 0
+_ST_OK, _ST_EMPTY, _ST_FAILED = 0, 1, 2
+
+
+def _wait_done(work) -> None:
+    """Host-side completion of a transfer.  ``Work.wait()`` on RCCL only makes the current torch stream wait; the buffers
+    these transfers read are rewritten by kernels on the library's own streams, so the host has to see them finished."""
+    import time
+    work.wait()
+    while not work.is_completed():
+        time.sleep(0.0002)
+
+
+def _p2p(op, tensor: torch.Tensor, peer: int):
+    """One point-to-point transfer, posted as a group of one (on RCCL: ncclGroupStart / ncclSend|ncclRecv / ncclGroupEnd on
+    the world communicator - no per-pair communicator is created); returns the work handles."""
+    return dist.batch_isend_irecv([dist.P2POp(op, tensor, peer)])
+
+
 def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optional[str] = None,
                  behaviors: Optional[Sequence[str]] = None, temperature: float = 1.0,
-                 progress_callback=None) -> Optional[List[dict]]:
+                 progress_callback=None, csv_threads: int = 2) -> Optional[List[dict]]:
     """Drain a list of videos on all ranks: what the reference's EncodeThread queue (+ ClassificationThread when a model
-    is live) does on one device (backend/workthreads.py:276-348, 453-519), sharded by clip.
+    is live) does on one device (backend/workthreads.py:276-348, 453-519), sharded by clip over one process per GPU.
 
-    Clip i belongs to rank i mod world (``shard_clips``).  The ranks walk the list in rounds of ``world`` clips: every
-    rank encodes its clip of the round with ``encode_file``'s chunk loop (and classifies it with ``infer_file``'s
-    window loop when ``head`` is given), then the rows are gathered to rank 0 (``gather_rows``), which writes
-    ``<video>_cls.h5`` (and ``<video>_<dataset_name>_outputs.csv``) in clip order with the reference's file semantics
-    (``.tmp`` + rename, encoder stamp, CSV header = behaviours).  A clip that fails on its rank is logged there and
-    skipped, as EncodeThread does (workthreads.py:334-336); a video without frames yields no file.
+    * **Queue.**  Every rank pulls the next clip index from a shared counter (``_ClipQueue``) when it is free - not a
+      static i mod N split, so one long clip does not stall the other GPUs.
+    * **Clip.**  ``pipeline.ClipRunner``: the chunk loop of ``encode_file`` feeding the window loop of ``infer_file``
+      inside the fused native session; the rows stay in HBM.
+    * **Gather.**  When a clip is done its rank publishes a ticket {rank, clip, rows, status} in the store and posts ONE
+      send of the fp16 rows (+ one of the probabilities) to rank 0 - straight from the session's device buffers on RCCL -
+      and goes on with its next clip (two sessions alternate, so the send drains under the next clip's kernels).  A
+      receiver thread on rank 0 takes the tickets in order and posts the matching receives: N-1 peers, N-1 xGMI links,
+      nothing padded, nothing broadcast, no rank waits at a round boundary.
+    * **Files.**  The receiver hands the rows to ``_OutputWriter`` (one HDF5 thread + a CSV pool); rank 0's own encode loop
+      never writes.  Files are what ``encode_file`` / ``infer_file`` write, byte for byte (``.tmp`` + rename, encoder
+      stamp, CSV header = behaviours), whatever rank encoded them and in whatever order they completed.
 
-    Returns on rank 0 one record per clip {"path", "frames", "cls_file", "csv_file", "status"}, status in
-    {"ok", "empty", "failed"}; ``None`` on the other ranks.  Every rank must call it with the same ``paths``."""
-    import numpy as np
+    A clip that fails on its rank is logged there and skipped, as EncodeThread does (workthreads.py:334-336); a video
+    without frames yields no file.  Returns on rank 0 one record per clip, in clip order, {"path", "frames", "cls_file",
+    "csv_file", "status", "rank"} with status in {"ok", "empty", "failed"}; ``None`` on the other ranks.  Every rank must call
+    it with the same ``paths``."""
+    import json
+    import threading
+    import time
     from . import pipeline as P
+    global _ef_calls
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    gloo = dist.is_initialized() and dist.get_backend() == "gloo"
-    dev = torch.device("cpu") if (gloo or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
+    nccl = world > 1 and dist.get_backend() == "nccl"
     paths = list(paths)
     if head is not None and (dataset_name is None or behaviors is None):
         raise ValueError("classification needs dataset_name and behaviors (infer_file's arguments)")
     D = encoder.config.hidden_size
-    results: List[dict] = []
-    for base in range(0, len(paths), world):
-        mine = base + rank
-        rows = probs = None
-        status = 3                                              # 0 ok, 1 empty video, 2 failed, 3 no clip this round
-        if mine < len(paths):
+    Cn = head.out_features if head is not None else 0
+    _ef_calls += 1
+    prefix = f"cbas/encode_files/{_ef_calls}/"
+    store = dist.distributed_c10d._get_default_store() if world > 1 else None
+    if world > 1:
+        barrier()          # every rank is here; on RCCL this also creates the communicator the transfers below share
+    queue_ = _ClipQueue(len(paths), store, prefix)
+    runner = P.ClipRunner(encoder, head, temperature, sessions=2 if nccl else 1)
+    dev = encoder.device if nccl else torch.device("cpu")
+
+    records = [{"path": p, "frames": 0, "cls_file": None, "csv_file": None, "status": "failed", "rank": None} for p in paths]
+    writer = receiver = None
+    local_done: dict = {}                                  # rank 0's own clips: clip -> (rows, probs) host arrays
+    recv_err: list = []
+    if rank == 0:
+        writer = _OutputWriter(records, dataset_name if head is not None else None, behaviors, P.file_attrs(encoder),
+                               csv_threads)
+
+        def take(t: dict):
+            clip, src, n = t["clip"], t["rank"], t["n"]
+            rec = records[clip]
+            rec["rank"] = src
+            rec["status"] = {_ST_OK: "ok", _ST_EMPTY: "empty", _ST_FAILED: "failed"}[t["status"]]
+            if t["status"] != _ST_OK:
+                return
+            if src == 0:
+                rows, probs = local_done.pop(clip)
+            else:
+                rows = torch.empty((n, D), dtype=torch.float16, device=dev)
+                probs = torch.empty((n, Cn), dtype=torch.float32, device=dev) if (Cn and t["probs"]) else None
+                if n:
+                    for w in _p2p(dist.irecv, rows, src):
+                        _wait_done(w)
+                    if probs is not None:
+                        for w in _p2p(dist.irecv, probs, src):
+                            _wait_done(w)
+                rows = rows.cpu().numpy()
+                probs = probs.cpu().numpy() if probs is not None else None
+            writer.submit(clip, rows, probs)
+
+        def receive():
             try:
-                rows = P.encode_rows(encoder, paths[mine], progress_callback)
-                if rows is None:
-                    status = 1
-                else:
-                    if head is not None and rows.shape[0] > 0:
-                        hdev = encoder.device if hasattr(encoder, "device") else dev
-                        probs = head.infer_clip(torch.from_numpy(rows).to(hdev), float(temperature)).cpu().numpy()
-                    status = 0
-            except Exception as e:  # noqa: BLE001 - the queue survives a bad file (workthreads.py:334-336)
-                print(f"ERROR during encoding for {paths[mine]} on rank {rank}: {e}")
-                rows = probs = None
-                status = 2
-        # round status of every rank (control plane), then the two row gathers
-        st = torch.tensor([status], dtype=torch.int64, device=dev)
-        if world > 1:
-            all_st = [torch.zeros_like(st) for _ in range(world)]
-            dist.all_gather(all_st, st)
-            all_st = [int(t.item()) for t in all_st]
+                if nccl:
+                    torch.cuda.set_device(dev)
+                # its own client connection: a blocking store call here must not hold up the encode loop's counter
+                st = store.clone() if store is not None and hasattr(store, "clone") else store
+                for k in range(len(paths)):                # exactly one ticket per clip
+                    key = f"{prefix}t{k}"
+                    while not (key in tickets if st is None else st.check([key])):
+                        if stop.is_set():
+                            return
+                        time.sleep(0.001)
+                    take(tickets.pop(key) if st is None else json.loads(st.get(key).decode()))
+            except BaseException as e:  # noqa: BLE001 - re-raised by the caller after the join
+                recv_err.append(e)
+
+        tickets: dict = {}                                 # world == 1: the store is a dict
+        stop = threading.Event()
+        receiver = threading.Thread(target=receive, name="cbas-gather", daemon=True)
+        receiver.start()
+
+    def publish(clip: int, status: int, n: int, has_probs: bool):
+        t = {"rank": rank, "clip": clip, "status": status, "n": int(n), "probs": bool(has_probs)}
+        if store is None:
+            tickets[f"{prefix}t{clip_seq[0]}"] = t
+            clip_seq[0] += 1
         else:
-            all_st = [status]
-        ok = status == 0
-        g_rows = gather_rows([torch.from_numpy(rows).to(dev)] if ok else [], dst=0)
-        g_probs = gather_rows([torch.from_numpy(probs).to(dev)] if ok and probs is not None else [], dst=0) if head is not None else None
-        if rank != 0:
-            continue
-        for r in range(world):
-            clip = base + r
-            if clip >= len(paths):
+            k = int(store.add(prefix + "done", 1)) - 1
+            store.set(f"{prefix}t{k}", json.dumps(t))
+
+    clip_seq = [0]
+    finished = False
+    sends: list = []                                       # work handles of this rank's sends (settled per session)
+    try:
+        while True:
+            clip = queue_.next()
+            if clip is None:
                 break
-            rec = {"path": paths[clip], "frames": 0, "cls_file": None, "csv_file": None,
-                   "status": {0: "ok", 1: "empty", 2: "failed"}[all_st[r]]}
-            if all_st[r] == 0:
-                try:
-                    r16 = g_rows[r][0].cpu().numpy()
-                    rec["frames"] = int(r16.shape[0])
-                    rec["cls_file"] = P.write_cls_file(paths[clip], r16)
-                    print(f"Successfully encoded {os.path.basename(paths[clip])} to {os.path.basename(rec['cls_file'])}")
-                    if head is not None and g_probs[r]:
-                        csv = rec["cls_file"].replace("_cls.h5", f"_{dataset_name}_outputs.csv")
-                        P.write_probs_csv(csv, g_probs[r][0].cpu().numpy(), list(behaviors))
-                        rec["csv_file"] = csv
-                except Exception as e:  # noqa: BLE001
-                    print(f"ERROR writing outputs of {paths[clip]}: {e}")
-                    rec["status"] = "failed"
-            results.append(rec)
-    return results if rank == 0 else None
+            try:
+                res = runner.run(paths[clip], None, progress_callback, device_out=nccl and rank != 0)
+            except Exception as e:  # noqa: BLE001 - the queue survives a bad file (workthreads.py:334-336)
+                print(f"ERROR during encoding for {paths[clip]} on rank {rank}: {e}")
+                publish(clip, _ST_FAILED, 0, False)
+                continue
+            if res is None:
+                publish(clip, _ST_EMPTY, 0, False)
+                continue
+            n, has_probs = res.frames, res.probs is not None
+            if rank == 0:
+                rows = res.rows.cpu().numpy() if res.on_device else res.rows
+                probs = (res.probs.cpu().numpy() if res.on_device else res.probs) if has_probs else None
+                local_done[clip] = (rows, probs)
+                publish(clip, _ST_OK, n, has_probs)
+                continue
+            publish(clip, _ST_OK, n, has_probs)
+            if n:
+                rows = res.rows if nccl else torch.from_numpy(res.rows) if not res.on_device else res.rows.cpu()
+                work = _p2p(dist.isend, rows.contiguous(), 0)
+                if has_probs:
+                    probs = res.probs if nccl else torch.from_numpy(res.probs) if not res.on_device else res.probs.cpu()
+                    work += _p2p(dist.isend, probs.contiguous(), 0)
+                res.pending.extend(lambda w=w: _wait_done(w) for w in work)     # before the session is reused
+                sends.append((work, rows, probs if has_probs else None))
+                sends[:] = [s_ for s_ in sends if not all(w.is_completed() for w in s_[0])]
+        for work, _r, _p in sends:
+            for w in work:
+                _wait_done(w)
+        finished = True
+    finally:
+        if rank == 0:
+            if not finished:
+                stop.set()                                 # an error is on its way up: do not wait for tickets that will not come
+            receiver.join()
+            writer.close()
+        runner.close()
+    if recv_err:
+        raise recv_err[0]
+    return records if rank == 0 else None
 
 
 _DT = [torch.float16, torch.float32, torch.uint8, torch.int64, torch.bfloat16]

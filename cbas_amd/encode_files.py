@@ -5,8 +5,9 @@
         [--dataset-name NAME] video1.mp4 video2.mp4 ...        (or --dir <recordings root>)
 
 What the reference does with its EncodeThread queue and, when a model is live, its ClassificationThread queue
-(backend/workthreads.py:276-348, 453-519) on one device: here clip i goes to rank i mod N, and rank 0 writes
-``<video>_cls.h5`` / ``<video>_<dataset>_outputs.csv`` exactly as ``encode_file`` / ``infer_file`` do.  Works unchanged
+(backend/workthreads.py:276-348, 453-519) on one device: here every rank pulls the next video from one shared queue,
+ships its rows to rank 0 over RCCL, and rank 0's writer threads produce ``<video>_cls.h5`` /
+``<video>_<dataset>_outputs.csv`` exactly as ``encode_file`` / ``infer_file`` do (cbas_amd/dist.py).  Works unchanged
 with one process (no torchrun).  With ``--dir`` the videos are those the reference would queue on project load
 (startup_page.py:80-126): every ``*.mp4`` without an up-to-date ``_cls.h5``.
 """
@@ -51,19 +52,29 @@ def main(argv=None) -> int:
     ap.add_argument("--dataset-name", default=None, help="<video>_<dataset-name>_outputs.csv (default: the bundle's name)")
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--max-frame", type=int, nargs=2, default=(256, 256))
-    ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2))
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2),
+                    help="0 fp16 (meets the 1e-3 CLS contract), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode "
+                         "(needs --experimental-fp8)")
+    ap.add_argument("--experimental-fp8", action="store_true",
+                    help="allow --precision 2: rows are ~6e-2 from the fp32 reference, NOT interchangeable with fp16 rows; "
+                         "the files are stamped '<encoder>#mx-fp8' + attr encoder_precision so that CBAS and this tool "
+                         "treat them as made by a different encoder")
     args = ap.parse_args(argv)
+    if args.precision == 2 and not args.experimental_fp8:
+        ap.error("--precision 2 writes MX-fp8 rows that heads trained on fp16 embeddings must not consume; "
+                 "pass --experimental-fp8 to write them (stamped as such)")
 
     from . import dist as cdist, pipeline as P
     from .bundle import load_model_bundle
     from .encoder import DinoEncoder
-    rank, world, local = cdist.init_from_env()
+    rank, world, local = cdist.init_from_env(os.environ.get("CBAS_DIST_BACKEND"))
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     videos = list(args.videos)
+    stamp = args.encoder + ("#" + P.FP8_TAG if args.precision == 2 else "")      # what pipeline.file_attrs writes
     if args.dir:
-        videos += find_videos(args.dir, args.encoder)
+        videos += find_videos(args.dir, stamp)
     if not videos:
         if rank == 0:
             print("nothing to encode")
@@ -73,7 +84,8 @@ def main(argv=None) -> int:
                       precision=args.precision)
     head = meta = None
     if args.model_bundle:
-        head, meta = load_model_bundle(args.model_bundle, device=device, project_encoder=args.encoder,
+        # an MX-fp8 run only accepts a head whose bundle says it was trained on MX-fp8 rows (same '#mx-fp8' stamp)
+        head, meta = load_model_bundle(args.model_bundle, device=device, project_encoder=stamp,
                                        in_features=enc.config.hidden_size)
         if head is None:
             return 2

@@ -114,6 +114,11 @@ class DinoEncoder:
         self._cfg_c.max_height, self._cfg_c.max_width = new
         self._create()
 
+    @property
+    def precision(self) -> int:
+        """0 fp16 (default), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode (include/cbas_mi355x.h)."""
+        return int(self._cfg_c.precision)
+
     # -- nn.Module-like surface used by the reference ------------------------------------------
     def eval(self):
         return self
@@ -126,7 +131,19 @@ class DinoEncoder:
     def parameters(self):
         return iter(())
 
+    def _register_session(self, session) -> None:
+        import weakref
+        if getattr(self, "_sessions", None) is None:
+            self._sessions = weakref.WeakSet()
+        self._sessions.add(session)
+
     def close(self):
+        # fused sessions drain through this handle when they are destroyed: close them while it still exists
+        for s in list(getattr(self, "_sessions", None) or ()):
+            try:
+                s.close()
+            except Exception:  # noqa: BLE001
+                pass
         if getattr(self, "_h", None):
             self._lib.cbas_enc_destroy(self._h)
             self._h = None
@@ -225,6 +242,10 @@ class DinoEncoder:
     def set_prune_last_layer(self, enable: bool) -> None:
         """Default on: the last layer computes q/attention/MLP for the CLS rows only (bit-identical CLS)."""
         _lib.check(self._lib.cbas_enc_set_prune_last_layer(self._h, int(bool(enable))), "cbas_enc_set_prune_last_layer")
+
+    def debug_option(self, name: str, value: int) -> None:
+        """Bring-up / tests: switch an implementation detail whose settings are bit-identical (cbas_enc_debug_option)."""
+        _lib.check(self._lib.cbas_enc_debug_option(self._h, name.encode(), int(value)), "cbas_enc_debug_option")
 
     def wait_stream(self, slot: int) -> None:
         """The current torch stream waits for ``slot``'s batch (no host synchronisation); frees the slot."""

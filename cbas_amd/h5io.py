@@ -112,6 +112,7 @@ class _HDF5:
         def glob_id(name):
             return hid_t.in_dll(L, name).value
         self.T_IEEE_F32LE = glob_id("H5T_IEEE_F32LE_g")
+        self.T_IEEE_F64LE = glob_id("H5T_IEEE_F64LE_g")
         self.T_C_S1 = glob_id("H5T_C_S1_g")
         self.P_DATASET_CREATE = glob_id("H5P_CLS_DATASET_CREATE_ID_g")
         # IEEE binary16 exactly as h5py defines its 'f2': sign 15, exponent 10..14 (bias 15), mantissa 0..9
@@ -135,18 +136,24 @@ def _dims(*v):
 class ClsWriter:
     """``with ClsWriter(tmp_path, dim, attrs) as w: w.append(rows_f16); w.flush()``"""
 
-    def __init__(self, path: str, dim: int, attrs: Optional[Dict[str, str]] = None):
+    def __init__(self, path: str, dim: int, attrs: Optional[Dict[str, str]] = None, dtype: str = "f2"):
+        """``dtype``: "f2" is what the reference writes (backend/cbas.py:420); "f4" / "f8" exist to make the foreign
+        files infer_file must also read (any numeric `cls` dataset, :507-508)."""
         self.path, self.dim, self.rows = path, int(dim), 0
         attrs = attrs or {}
+        if dtype not in ("f2", "f4", "f8"):
+            raise ValueError(f"dtype {dtype!r}: f2, f4 or f8")
+        self._np = np.dtype(dtype)
         if _h5py is not None:
             self._f = _h5py.File(path, "w")
             for k, v in attrs.items():
                 self._f.attrs[k] = v
-            self._d = self._f.create_dataset("cls", shape=(0, dim), maxshape=(None, dim), dtype="f2",
+            self._d = self._f.create_dataset("cls", shape=(0, dim), maxshape=(None, dim), dtype=dtype,
                                              chunks=(CHUNK_ROWS, dim))
             self._h = None
             return
         H = self._h = _HDF5.get()
+        self._t = {"f2": H.T_F16, "f4": H.T_IEEE_F32LE, "f8": H.T_IEEE_F64LE}[dtype]
         self._fid = H.Fcreate(path.encode(), 2, 0, 0)            # H5F_ACC_TRUNC
         if self._fid < 0:
             raise OSError(f"cannot create HDF5 file {path}")
@@ -164,7 +171,7 @@ class ClsWriter:
         # h5py creates datasets with track_times=False (what the reference's files look like): no creation / modification
         # timestamps in the object header, so equal rows give byte-identical files
         H.Pset_obj_track_times(pl, 0)
-        self._did = H.Dcreate2(self._fid, b"cls", H.T_F16, sp, 0, pl, 0)
+        self._did = H.Dcreate2(self._fid, b"cls", self._t, sp, 0, pl, 0)
         H.Pclose(pl); H.Sclose(sp)
         if self._did < 0:
             H.Fclose(self._fid)
@@ -172,8 +179,8 @@ class ClsWriter:
 
     def append(self, rows: np.ndarray) -> None:
         rows = np.ascontiguousarray(rows)
-        if rows.dtype != np.float16:
-            rows = rows.astype(np.float16)            # IEEE round-to-nearest-even, as h5py's f4 -> f2 write
+        if rows.dtype != self._np:
+            rows = rows.astype(self._np)              # IEEE round-to-nearest-even, as h5py's f4 -> f2 write
         n = rows.shape[0]
         if n == 0:
             return
@@ -188,7 +195,7 @@ class ClsWriter:
             fs = H.Dget_space(self._did)
             H.Sselect_hyperslab(fs, 0, _dims(self.rows, 0), None, _dims(n, self.dim), None)
             ms = H.Screate_simple(2, _dims(n, self.dim), None)
-            rc = H.Dwrite(self._did, H.T_F16, ms, fs, 0, rows.ctypes.data)
+            rc = H.Dwrite(self._did, self._t, ms, fs, 0, rows.ctypes.data)
             H.Sclose(ms); H.Sclose(fs)
             if rc < 0:
                 raise OSError("H5Dwrite failed")
@@ -219,7 +226,9 @@ class ClsWriter:
 
 
 class ClsReader:
-    """Read access to a ``_cls.h5``: ``.shape``, ``.attrs`` (dict of str), ``read(a, b)`` -> float16 rows."""
+    """Read access to a ``_cls.h5``: ``.shape``, ``.attrs`` (dict of str), ``read(a, b)`` -> rows [a, b) as float16 when
+    the dataset is IEEE half (what encode_file writes; a byte copy), else as float32 (the reference reads any numeric
+    dtype and converts with ``.float()``: backend/cbas.py:507-508)."""
 
     def __init__(self, path: str):
         self.path = path
@@ -228,6 +237,7 @@ class ClsReader:
             self._d = self._f["cls"]
             self.shape = tuple(self._d.shape)
             self.itemsize = self._d.dtype.itemsize
+            self.is_half = self._d.dtype == np.float16
             self.attrs = {k: (v.decode() if isinstance(v, bytes) else str(v)) for k, v in self._f.attrs.items()}
             self._h = None
             return
@@ -247,9 +257,10 @@ class ClsReader:
         self.shape = tuple(int(x) for x in dims[:nd])
         t = H.Dget_type(self._did)
         self.itemsize = int(H.Tget_size(t))
+        self.is_half = self.itemsize == 2 and H.Tget_class(t) == 1        # H5T_FLOAT
         H.Tclose(t)
         self.attrs = {}
-        for k in ("encoder_model_identifier", "schema_version"):
+        for k in ("encoder_model_identifier", "schema_version", "encoder_precision"):
             if H.Aexists(self._fid, k.encode()) > 0:
                 self.attrs[k] = self._read_str_attr(k)
 
@@ -280,15 +291,16 @@ class ClsReader:
         n = max(0, stop - start)
         if self._h is None:
             a = self._d[start:stop]
-            return a if a.dtype == np.float16 else a.astype(np.float16)
-        out = np.empty((n, self.shape[1]), np.float16)
+            return a if a.dtype == np.float16 else a.astype(np.float32)
+        out = np.empty((n, self.shape[1]), np.float16 if self.is_half else np.float32)
         if n == 0:
             return out
         H = self._h
         fs = H.Dget_space(self._did)
         H.Sselect_hyperslab(fs, 0, _dims(start, 0), None, _dims(n, self.shape[1]), None)
         ms = H.Screate_simple(2, _dims(n, self.shape[1]), None)
-        rc = H.Dread(self._did, H.T_F16, ms, fs, 0, out.ctypes.data)   # file f2 -> memory f2: a byte copy
+        # file f2 -> memory f2 is a byte copy; any other numeric file type is converted to float32 by the library
+        rc = H.Dread(self._did, H.T_F16 if self.is_half else H.T_IEEE_F32LE, ms, fs, 0, out.ctypes.data)
         H.Sclose(ms); H.Sclose(fs)
         if rc < 0:
             raise OSError(f"H5Dread failed on {self.path}")

@@ -171,30 +171,36 @@ class ClassifierLSTMDeltas:
         return logits, latent
 
     # -- whole-clip sliding-window inference --------------------------------------------------------
-    def infer_clip(self, cls_f16: torch.Tensor, temperature: float = 1.0, want_logits: bool = False):
-        """cls_f16 (N, in_features) float16 on the device -> probs (N, C) float32 [, logits]."""
+    def infer_clip(self, cls_rows: torch.Tensor, temperature: float = 1.0, want_logits: bool = False):
+        """cls_rows (N, in_features) on the device, float16 (what ``_cls.h5`` holds) or float32 (a foreign ``cls``
+        dataset after the reference's ``.float()``, backend/cbas.py:507-508) -> probs (N, C) float32 [, logits]."""
         self._ensure()
-        assert cls_f16.dtype == torch.float16 and cls_f16.is_cuda and cls_f16.dim() == 2
-        cls_f16 = cls_f16.contiguous()
-        n = cls_f16.shape[0]
+        assert cls_rows.dtype in (torch.float16, torch.float32) and cls_rows.is_cuda and cls_rows.dim() == 2
+        cls_rows = cls_rows.contiguous()
+        n = cls_rows.shape[0]
         probs = torch.empty((n, self.out_features), dtype=torch.float32, device=self.device)
         logits = torch.empty((n, self.out_features), dtype=torch.float32, device=self.device) if want_logits else None
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._lib.cbas_head_infer_f16(self._h, cls_f16.data_ptr(), n, float(temperature), probs.data_ptr(),
-                                                 logits.data_ptr() if want_logits else None, stream),
-                   "cbas_head_infer_f16")
+        if n:
+            self._range(cls_rows, n, 0, n, probs, logits, temperature)
         return (probs, logits) if want_logits else probs
 
-
-    def infer_range_into(self, cls_f16: torch.Tensor, n_frames: int, first: int, count: int,
-                         probs_out: torch.Tensor, temperature: float = 1.0) -> None:
-        """Classify frames [first, first+count) of a clip whose first ``n_frames`` CLS rows are in
-        ``cls_f16``; writes ``probs_out[first:first+count]`` (asynchronous on the current stream)."""
-        self._ensure()
+    def _range(self, rows: torch.Tensor, n_frames: int, first: int, count: int, probs: Optional[torch.Tensor],
+               logits: Optional[torch.Tensor], temperature: float) -> None:
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._lib.cbas_head_infer_f16_range(
-            self._h, cls_f16.data_ptr(), n_frames, first, count, float(temperature),
-            probs_out[first:first + count].data_ptr(), None, stream), "cbas_head_infer_f16_range")
+        half_rows = rows.dtype == torch.float16
+        fn = self._lib.cbas_head_infer_f16_range if half_rows else self._lib.cbas_head_infer_f32_range
+        _lib.check(fn(self._h, rows.data_ptr(), n_frames, first, count, float(temperature),
+                      probs.data_ptr() if probs is not None else None,
+                      logits.data_ptr() if logits is not None else None, stream),
+                   "cbas_head_infer_f16_range" if half_rows else "cbas_head_infer_f32_range")
+
+    def infer_range_into(self, cls_rows: torch.Tensor, n_frames: int, first: int, count: int,
+                         probs_out: torch.Tensor, temperature: float = 1.0) -> None:
+        """Classify frames [first, first+count) of a clip whose first ``n_frames`` CLS rows (float16 or float32) are in
+        ``cls_rows``; writes ``probs_out[first:first+count]`` (asynchronous on the current stream)."""
+        self._ensure()
+        assert cls_rows.dtype in (torch.float16, torch.float32) and cls_rows.is_contiguous()
+        self._range(cls_rows, n_frames, first, count, probs_out[first:first + count], None, temperature)
 
 
 def from_reference_module(module, device) -> ClassifierLSTMDeltas:

@@ -12,11 +12,13 @@ once per materialised window.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import shutil
+import threading
 import traceback
 from collections import deque
-from typing import Callable, List, Optional
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -49,6 +51,31 @@ class NpyFrameSource:
         if idx and idx == list(range(idx[0], idx[0] + len(idx))):
             return np.ascontiguousarray(self._a[idx[0]:idx[0] + len(idx)])
         return np.ascontiguousarray(self._a[idx])
+
+    frame_shape = property(lambda self: tuple(self._a.shape[1:]))
+
+    def read_into(self, start: int, stop: int, out: np.ndarray) -> None:
+        """Frames [start, stop) straight from the page cache into ``out`` (a page-locked buffer): one copy, split over
+        a few threads when it is large (numpy releases the GIL while it copies; one thread moves ~4 GB/s, and a GPU that
+        encodes 22 k frames/s consumes 3.3 GB/s of 224 x 224 RGB)."""
+        n = stop - start
+        if n * int(np.prod(self._a.shape[1:])) < (16 << 20) or n < 4:
+            np.copyto(out, self._a[start:stop])
+            return
+        cuts = [start + (n * k) // 4 for k in range(5)]
+        list(_copy_pool().map(lambda ab: np.copyto(out[ab[0] - start:ab[1] - start], self._a[ab[0]:ab[1]]),
+                              zip(cuts[:-1], cuts[1:])))
+
+
+_COPY_POOL = None
+
+
+def _copy_pool():
+    global _COPY_POOL
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="cbas-copy")
+    return _COPY_POOL
 
 
 class ArrayFrameSource:
@@ -115,6 +142,25 @@ def _current_stamp() -> Optional[str]:
     except Exception:  # noqa: BLE001
         pass
     return None
+
+
+FP8_TAG = "mx-fp8"
+
+
+def file_attrs(encoder=None) -> dict:
+    """Root attributes of a ``_cls.h5`` (backend/cbas.py:414-416): the project's encoder stamp + schema version when a
+    project is set.  Rows made in the MX-fp8 throughput mode (precision 2) are NOT interchangeable with fp16 rows (CLS
+    error ~6e-2 against the 1e-3 contract), so such files say so: an ``encoder_precision`` attribute, and a stamp with a
+    ``#mx-fp8`` suffix - the reference's project loader (startup_page.py:100-117) and its model loader
+    (workthreads.py:390-399) then treat them as made by a different encoder instead of consuming them silently."""
+    fp8 = int(getattr(encoder, "precision", 0) or 0) == 2
+    attrs = {}
+    stamp = _current_stamp()
+    if stamp:
+        attrs = {"encoder_model_identifier": stamp + ("#" + FP8_TAG if fp8 else ""), "schema_version": SCHEMA_VERSION}
+    if fp8:
+        attrs["encoder_precision"] = FP8_TAG
+    return attrs
 
 
 def encode_file(encoder: DinoEncoder, path: str, progress_callback=None, reader=None) -> Optional[str]:
@@ -189,11 +235,7 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
     D = encoder.config.hidden_size
     nslots = _lib.ENC_SLOTS
     try:
-        attrs = {}
-        stamp = _current_stamp()
-        if stamp:
-            attrs = {"encoder_model_identifier": stamp, "schema_version": SCHEMA_VERSION}
-        with h5io.ClsWriter(tmp_file_path, D, attrs) as w_sync:
+        with h5io.ClsWriter(tmp_file_path, D, file_attrs(encoder)) as w_sync:
             w = _WriterThread(w_sync)
             try:
                 _stream_chunks(encoder, reader, video_len, progress_callback, w, nslots)
@@ -263,20 +305,18 @@ def encode_rows(encoder: DinoEncoder, path: str, progress_callback=None, reader=
             reader.close()
 
 
-def write_cls_file(video_path: str, rows: np.ndarray) -> str:
+def write_cls_file(video_path: str, rows: np.ndarray, attrs: Optional[dict] = None) -> str:
     """Write ``<video>_cls.h5`` for already-encoded rows with encode_file's file semantics (backend/cbas.py:410-421,
-    442): ``.tmp`` first, stamp attributes when a project is set, atomic rename; the ``.tmp`` is removed on failure."""
+    442): ``.tmp`` first, stamp attributes when a project is set (``attrs`` = ``file_attrs(encoder)``; default: those of
+    an fp16 encoder), atomic rename; the ``.tmp`` is removed on failure."""
     out_file_path = os.path.splitext(video_path)[0] + "_cls.h5"
     tmp_file_path = out_file_path + ".tmp"
-    attrs = {}
-    stamp = _current_stamp()
-    if stamp:
-        attrs = {"encoder_model_identifier": stamp, "schema_version": SCHEMA_VERSION}
+    if attrs is None:
+        attrs = file_attrs(None)
     try:
         with h5io.ClsWriter(tmp_file_path, rows.shape[1], attrs) as w:
-            for i in range(0, rows.shape[0], CHUNK_SIZE):            # same append granularity as the chunk loop
-                w.append(rows[i:i + CHUNK_SIZE])
-                w.flush()
+            w.append(rows)           # the file's bytes do not depend on the append granularity (chunks are 8192 rows
+            w.flush()                # either way; tests/test_host_logic.py compares with the 512-row chunk loop)
         os.replace(tmp_file_path, out_file_path)
     except Exception:
         if os.path.exists(tmp_file_path):
@@ -288,22 +328,80 @@ def write_cls_file(video_path: str, rows: np.ndarray) -> str:
     return out_file_path
 
 
-class _ChunkPrefetcher:
-    """Decode ahead: ``reader.get_batch`` for chunk k+1 (and k+2) runs on a background thread while chunk k is being
-    staged and encoded.  The reference decodes, converts, copies and computes strictly in turn (cbas.py:425-438); with
-    the ViT ~100x faster the decoder (decord's libav call releases the GIL) is what has to be kept busy.  Works with any
-    reader that has ``get_batch``; chunks are delivered in order, a decoder error is re-raised at the chunk it
-    belongs to.  Readers that already decode ahead on their own thread (``PipeFrameSource``) are used directly."""
+class _PinnedRing:
+    """Page-locked chunk buffers the decode-ahead thread fills.  A sub-batch pushed from page-locked memory is DMA'd
+    straight from it (cbas_enc_submit_u8_host: no staging copy on the submitting thread), so a buffer goes back to the
+    decoder only once the consumer says its copies are done (``release``).  Buffers are kept per byte size for the life of
+    the process: hipHostMalloc of ~80 MB costs milliseconds, a directory of videos would pay it per file."""
 
-    def __init__(self, reader, video_len: int, depth: int = 2):
+    _lock = threading.Lock()
+    _pool: dict = {}                 # nbytes -> [torch uint8 tensors]
+    def __init__(self, nbytes: int, depth: int = 4):
+        self.nbytes, self.depth = int(nbytes), int(depth)       # depth 4: one being consumed, two queued, one being filled
+        with self._lock:
+            have = self._pool.setdefault(self.nbytes, [])
+            self._bufs = [have.pop() for _ in range(min(len(have), self.depth))]
+        while len(self._bufs) < self.depth:
+            self._bufs.append(torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True))
+        self._free = deque(range(self.depth))
+        self._cv = threading.Condition()
+
+    def acquire(self, stop: threading.Event) -> Optional[int]:
+        with self._cv:
+            while not self._free:
+                if stop.is_set():
+                    return None
+                self._cv.wait(0.05)
+            return self._free.popleft()
+
+    def release(self, k: int) -> None:
+        with self._cv:
+            self._free.append(k)
+            self._cv.notify()
+
+    def view(self, k: int, shape: Tuple[int, ...]) -> np.ndarray:
+        n = int(np.prod(shape))
+        return self._bufs[k].numpy()[:n].reshape(shape)
+
+    def give_back(self) -> None:
+        with self._lock:
+            have = self._pool.setdefault(self.nbytes, [])
+            if len(have) < 2 * self.depth:
+                have.extend(self._bufs)
+        self._bufs = []
+
+
+class _ChunkStream:
+    """``for start, end, frames in stream`` over the 512-frame chunks of a video (backend/cbas.py:423-425), decoded
+    ahead: ``reader.get_batch`` for chunks k+1 and k+2 runs on a background thread while chunk k is being staged and
+    encoded.  The reference decodes, converts, copies and computes strictly in turn (cbas.py:425-438); with the ViT ~100x
+    faster the decoder (decord's libav call releases the GIL) is what has to be kept busy.  Works with any reader that has
+    ``get_batch``; chunks are delivered in order, a decoder error is re-raised at the chunk it belongs to.  Readers that
+    already decode ahead on their own thread (``PipeFrameSource``) are read directly.
+
+    ``pinned=True`` (real encoder on a GPU): chunks are delivered as views of page-locked ring buffers; the consumer
+    calls ``release(frames)`` when every host->HBM copy that reads a chunk has completed."""
+
+    def __init__(self, reader, video_len: int, pinned: bool = False, depth: int = 2, piece: int = CHUNK_SIZE):
         import queue
-        import threading
-        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._reader, self._n = reader, int(video_len)
+        # frames per delivery: the reference's 512-frame chunk (backend/cbas.py:48) unless the caller asks for smaller
+        # pieces - the encode loops do, so that the GPU starts after 128 frames have been decoded, not 512, and the
+        # last piece's tail is short (a clip's fixed latency; a divisor of the chunk so progress / flush points are kept)
+        self._piece = int(piece) if 0 < int(piece) <= CHUNK_SIZE and CHUNK_SIZE % int(piece) == 0 else CHUNK_SIZE
+        depth = depth * (CHUNK_SIZE // self._piece)
+        self._direct = bool(getattr(reader, "decodes_ahead", False)) or os.environ.get("CBAS_DECODE_AHEAD") == "0"
+        self._pinned = bool(pinned) and not self._direct and torch.cuda.is_available()
+        self._ring: Optional[_PinnedRing] = None
+        self._tokens: dict = {}                      # data address of a delivered chunk -> ring buffer index
         self._stop = threading.Event()
-        self._reader, self._n = reader, video_len
-        self._t = threading.Thread(target=self._run, name="cbas-decode-ahead", daemon=True)
-        self._t.start()
+        self._t = None
+        if not self._direct:
+            self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+            self._t = threading.Thread(target=self._run, name="cbas-decode-ahead", daemon=True)
+            self._t.start()
 
+    # -- producer ---------------------------------------------------------------------------------
     def _put(self, item) -> bool:
         import queue
         while not self._stop.is_set():
@@ -314,81 +412,291 @@ class _ChunkPrefetcher:
                 continue
         return False
 
+    def _decode(self, i: int, end: int):
+        """One chunk, in a ring buffer when there is one; returns (frames, ring index or None)."""
+        r = self._reader
+        if not self._pinned:
+            return r.get_batch(range(i, end)), None
+        shape = getattr(r, "frame_shape", None)
+        arr = None
+        if shape is None or not hasattr(r, "read_into"):
+            arr = r.get_batch(range(i, end))                     # learn the frame shape from the decoder's output
+            shape = tuple(arr.shape[1:])
+        if self._ring is None:
+            self._ring = _PinnedRing(self._piece * int(np.prod(shape)), depth=self._q.maxsize + 2 + _lib.ENC_SLOTS)
+        k = self._ring.acquire(self._stop)
+        if k is None:
+            return None, None
+        out = self._ring.view(k, (end - i,) + tuple(shape))
+        if arr is None:
+            r.read_into(i, end, out)
+        else:
+            np.copyto(out, arr)
+        return out, k
+
     def _run(self):
-        for i in range(0, self._n, CHUNK_SIZE):
-            end = min(i + CHUNK_SIZE, self._n)
+        for i in range(0, self._n, self._piece):
+            end = min(i + self._piece, self._n)
             try:
-                item = (i, end, self._reader.get_batch(range(i, end)))
+                frames, k = self._decode(i, end)
+                if frames is None:
+                    return
+                item = (i, end, frames, k)
             except BaseException as e:  # noqa: BLE001 - delivered to the consumer in order
-                self._put((i, end, e))
+                self._put((i, end, e, None))
                 return
             if not self._put(item):
                 return
 
+    # -- consumer ---------------------------------------------------------------------------------
     def __iter__(self):
-        for _ in range(0, self._n, CHUNK_SIZE):
-            i, end, frames = self._q.get()
+        for i in range(0, self._n, self._piece):
+            if self._direct:
+                end = min(i + self._piece, self._n)
+                yield i, end, self._reader.get_batch(range(i, end))
+                continue
+            i, end, frames, k = self._q.get()
             if isinstance(frames, BaseException):
                 raise frames
+            if k is not None:
+                self._tokens[frames.ctypes.data] = k
             yield i, end, frames
 
+    def release(self, frames: np.ndarray) -> None:
+        """The copies out of this chunk are done (no-op for chunks that are not ring buffers)."""
+        k = self._tokens.pop(frames.ctypes.data, None)
+        if k is not None and self._ring is not None:
+            self._ring.release(k)
+
     def close(self):
+        """Stop and JOIN the decode-ahead thread (so that the caller may close the reader afterwards)."""
         self._stop.set()
-        while True:                                  # unblock a producer waiting on a full queue
-            try:
-                self._q.get_nowait()
-            except Exception:  # noqa: BLE001
-                break
-        self._t.join(timeout=5)
+        if self._t is not None:
+            while True:                                  # unblock a producer waiting on a full queue
+                try:
+                    self._q.get_nowait()
+                except Exception:  # noqa: BLE001
+                    break
+            self._t.join(timeout=30)
+            self._t = None
+        if self._ring is not None:
+            self._ring.give_back()
+            self._ring = None
 
 
-def _chunks(reader, video_len: int):
-    """(start, end, frames) per 512-frame chunk, decoded ahead unless the reader does that itself."""
-    if getattr(reader, "decodes_ahead", False) or os.environ.get("CBAS_DECODE_AHEAD") == "0":
-        for i in range(0, video_len, CHUNK_SIZE):
-            end = min(i + CHUNK_SIZE, video_len)
-            yield i, end, reader.get_batch(range(i, end))
-        return
-    pf = _ChunkPrefetcher(reader, video_len)
-    try:
-        yield from pf
-    finally:
-        pf.close()
+PIECE = 128          # frames per decode-ahead delivery on the GPU paths (see _ChunkStream)
+
+
+def _chunks(reader, video_len: int, pinned: bool = False, piece: int = CHUNK_SIZE) -> _ChunkStream:
+    """(start, end, frames) per 512-frame chunk (or ``piece`` frames), decoded ahead unless the reader does that itself."""
+    return _ChunkStream(reader, video_len, pinned, piece=piece)
+
+
+def _progress(progress_callback, start: int, video_len: int) -> None:
+    """The reference reports once per 512-frame chunk, before the chunk is computed (backend/cbas.py:427-429)."""
+    if progress_callback and start % CHUNK_SIZE == 0:
+        progress_callback((min(start + CHUNK_SIZE, video_len) / video_len) * 100)
+
+
+def _wants_pinned(encoder) -> bool:
+    return getattr(encoder, "_h", None) is not None and getattr(encoder, "device", None) is not None \
+        and encoder.device.type == "cuda"
 
 
 def _stream_chunks(encoder: DinoEncoder, reader, video_len: int, progress_callback, w, nslots: int) -> None:
     """The chunk loop of encode_file (cbas.py:423-440) on the asynchronous slots."""
-    inflight: deque = deque()        # (slot, n_frames) in submission order
+    inflight: deque = deque()        # (slot, chunk frames) in submission order
     free = list(range(nslots))
-    keep: List[np.ndarray] = []      # keep chunk arrays alive until their sub-batches are staged
+    left: dict = {}                  # id(chunk frames) -> [frames, sub-batches not yet waited for]
 
     def drain_one():
-        slot, _n = inflight.popleft()
-        rows, _ = encoder.wait(slot)
+        slot, fr = inflight.popleft()
+        rows, _ = encoder.wait(slot)                 # host wait: this sub-batch's H2D copy is long done
         w.append(rows)
         free.append(slot)
+        ent = left[id(fr)]
+        ent[1] -= 1
+        if ent[1] == 0:
+            del left[id(fr)]
+            chunks.release(fr)
 
-    for i, end_index, frames_np in _chunks(reader, video_len):     # (n,H,W,3) uint8, host; decoded ahead
-        if progress_callback:
-            progress_callback((end_index / video_len) * 100)
-        frames_np = np.ascontiguousarray(frames_np)
-        keep = [frames_np]
-        for j in range(0, frames_np.shape[0], encoder.max_batch):
-            if not free:
-                drain_one()
-            slot = free.pop(0)
-            sub = frames_np[j:j + encoder.max_batch]
-            encoder.submit_host(slot, sub, channel=1)          # green channel, cbas.py:431
-            inflight.append((slot, sub.shape[0]))
-        # the reference flushes once per 512-frame chunk (cbas.py:440); results of this chunk
-        # may still be in flight, so flush what has landed and keep streaming
-        while len(inflight) > nslots - 1:
+    native = _wants_pinned(encoder)
+    chunks = _chunks(reader, video_len, pinned=native, piece=PIECE if native else CHUNK_SIZE)
+    with contextlib.closing(chunks):                 # the decode-ahead thread is joined before the caller closes the reader
+        for i, end_index, frames_np in chunks:       # (n,H,W,3) uint8, host; decoded ahead
+            _progress(progress_callback, i, video_len)
+            frames_np = np.ascontiguousarray(frames_np)
+            nsub = -(-frames_np.shape[0] // encoder.max_batch)
+            left[id(frames_np)] = [frames_np, nsub]
+            for j in range(0, frames_np.shape[0], encoder.max_batch):
+                if not free:
+                    drain_one()
+                slot = free.pop(0)
+                sub = frames_np[j:j + encoder.max_batch]
+                encoder.submit_host(slot, sub, channel=1)          # green channel, cbas.py:431
+                inflight.append((slot, frames_np))
+            # the reference flushes once per 512-frame chunk (cbas.py:440); results of this chunk
+            # may still be in flight, so flush what has landed and keep streaming
+            if end_index % CHUNK_SIZE == 0 or end_index == video_len:
+                while len(inflight) > nslots - 1:
+                    drain_one()
+                w.flush()
+        while inflight:
             drain_one()
         w.flush()
-    while inflight:
-        drain_one()
-    w.flush()
-    del keep
+
+
+class ClipResult:
+    """Rows of one video: ``rows`` (N, D) float16 and ``probs`` (N, C) float32 or None, as numpy arrays in host memory or
+    (``on_device``) as torch views of the session's device buffers, valid until that session's next clip; ``pending`` =
+    work that still reads those views (e.g. in-flight sends), waited for before the session is reused."""
+
+    def __init__(self, rows, probs, on_device: bool, pending: Optional[list] = None):
+        self.rows, self.probs, self.on_device = rows, probs, on_device
+        self.pending = pending if pending is not None else []
+
+    @property
+    def frames(self) -> int:
+        return int(self.rows.shape[0])
+
+
+class ClipRunner:
+    """One video at a time through the fused native session (cbas_fused_*, csrc/api_fused.hip): the chunk loop of
+    encode_file (backend/cbas.py:423-440) feeding the window loop of infer_file (:497-551) without the CLS rows leaving
+    HBM in between - what the reference does as EncodeThread -> ``_cls.h5`` -> ClassificationThread
+    (backend/workthreads.py:316-328, 488-498).  Frames are decoded ahead into page-locked ring buffers and DMA'd from
+    there; the results are bit-identical to ``encode_file`` followed by ``infer_file``.  ``head=None``: encode only.
+
+    Stand-in encoders without a native handle (the CPU tests' stubs) go through ``encode_rows`` + ``head.infer_clip``."""
+
+    def __init__(self, encoder, head=None, temperature: float = 1.0, sessions: int = 1):
+        self.encoder, self.head, self.temperature = encoder, head, float(temperature)
+        self.native = _wants_pinned(encoder)
+        self._sessions: list = [None] * max(1, int(sessions))       # [ClipStream, pending list] per slot
+        self._next = 0
+
+    def close(self) -> None:
+        for ent in self._sessions:
+            if ent is not None:
+                self._settle(ent[1])
+                ent[0].close()
+        self._sessions = [None] * len(self._sessions)
+
+    @staticmethod
+    def _settle(pending: list) -> None:
+        while pending:
+            w = pending.pop()
+            w.wait() if hasattr(w, "wait") else w()
+
+    def _session(self, capacity: int):
+        from .stream import ClipStream
+        k = self._next
+        self._next = (self._next + 1) % len(self._sessions)
+        ent = self._sessions[k]
+        if ent is not None:
+            self._settle(ent[1])                      # nothing may still read the buffers this clip overwrites
+        if ent is None or ent[0]._h is None or ent[0].capacity < capacity or ent[0].temperature != self.temperature:
+            cap = max(capacity, 4096)                 # the softmax temperature is fixed when a session is created
+            if ent is not None:
+                cap = max(cap, 2 * ent[0].capacity if ent[0].capacity < capacity else ent[0].capacity)
+                ent[0].close()
+            ent = self._sessions[k] = [ClipStream(self.encoder, self.head, cap, self.temperature), []]
+        ent[0].reset()
+        return ent
+
+    def run(self, path: str, reader=None, progress_callback=None, device_out: bool = False) -> Optional[ClipResult]:
+        """Encode (and classify) one video; ``None`` for a video without frames.  Reader / encoder errors propagate with
+        the encoder left reusable."""
+        if not self.native:
+            rows = encode_rows(self.encoder, path, progress_callback, reader)
+            if rows is None:
+                return None
+            probs = None
+            if self.head is not None and rows.shape[0] > 0:
+                probs = self.head.infer_clip(torch.from_numpy(rows), self.temperature).cpu().numpy()
+            return ClipResult(rows, probs, False)
+        own_reader = reader is None
+        reader = reader if reader is not None else open_video(path)
+        try:
+            video_len = len(reader)
+            if video_len == 0:
+                print(f"Warning: Video {path} contains no frames. Skipping.")
+                return None
+            return self._run_native(reader, video_len, progress_callback, device_out)
+        finally:
+            if own_reader and hasattr(reader, "close"):
+                reader.close()
+
+    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool) -> ClipResult:
+        enc = self.encoder
+        ent = None
+        sub = 0                                      # sub-batches submitted so far
+        held: deque = deque()                        # (chunk frames, sub-batch count after which its copies are done)
+        chunks = _chunks(reader, video_len, pinned=True, piece=PIECE)
+        with contextlib.closing(chunks):
+            for i, _end_index, frames in chunks:
+                _progress(progress_callback, i, video_len)
+                frames = np.ascontiguousarray(frames)
+                if ent is None:
+                    enc._fit_frame(frames.shape[1], frames.shape[2])     # may rebuild the handle (closes sessions)
+                    ent = self._session(video_len)
+                ent[0].push_host(frames, channel=1)                      # green channel, cbas.py:431
+                sub += -(-frames.shape[0] // enc.max_batch)
+                # a slot's previous host->HBM copy has completed when the slot is submitted to again, i.e. ENC_SLOTS
+                # sub-batches later (cbas_enc_submit_u8_host_dev): only then may the decoder refill this chunk's buffer
+                held.append((frames, sub + _lib.ENC_SLOTS))
+                while held and held[0][1] <= sub:
+                    chunks.release(held.popleft()[0])
+            sess = ent[0]
+            if device_out:
+                rows, probs = sess.finish()
+                torch.cuda.current_stream(enc.device).synchronize()      # every copy out of the ring has completed
+                res = ClipResult(rows, probs if self.head is not None else None, True, ent[1])
+            else:
+                rows, probs = sess.finish_host()
+                res = ClipResult(rows, probs if self.head is not None else None, False)
+            while held:
+                chunks.release(held.popleft()[0])
+        return res
+
+
+_runner_cache: dict = {}
+
+
+def _runner_for(encoder, head, temperature: float) -> ClipRunner:
+    """One cached runner (device clip buffers) per live (encoder, head) pair."""
+    import weakref
+    key = (id(encoder), id(head))
+    hit = _runner_cache.get(key)
+    if hit is None or hit[0]() is not encoder or (head is not None and hit[1]() is not head):
+        for k in [k for k, v in _runner_cache.items() if v[0]() is None or k == key]:
+            _runner_cache.pop(k)[2].close()
+        hit = _runner_cache[key] = (weakref.ref(encoder), weakref.ref(head) if head is not None else None,
+                                    ClipRunner(encoder, head, temperature))
+    hit[2].temperature = float(temperature)
+    return hit[2]
+
+
+def encode_infer_file(encoder: DinoEncoder, model, path: str, dataset_name: str, behaviors: List[str],
+                      temperature: float = 1.0, progress_callback=None, reader=None) -> Tuple[Optional[str], Optional[str]]:
+    """``encode_file`` + ``infer_file`` in one pass: returns (``<video>_cls.h5``, ``<video>_<dataset>_outputs.csv``), both
+    byte-identical to what the two calls write, (None, None) for a video without frames.  This is what the reference's
+    EncodeThread + ClassificationThread pair does for a video while a model is live (backend/workthreads.py:316-328,
+    488-498), without writing the rows out and reading them back first.  Raises like ``encode_file`` (nothing is left
+    behind but a removed ``.tmp``)."""
+    if not isinstance(encoder, DinoEncoder):
+        raise TypeError(f"cbas_amd.encode_infer_file needs a cbas_amd.DinoEncoder; got {type(encoder).__name__}")
+    head = _as_mi355x_head(model, encoder.device)
+    if len(behaviors) != head.out_features:
+        raise ValueError(f"{len(behaviors)} behaviour names for {head.out_features} model outputs")
+    res = _runner_for(encoder, head, temperature).run(path, reader, progress_callback)
+    if res is None:
+        return None, None
+    cls_path = write_cls_file(path, res.rows, file_attrs(encoder))
+    print(f"Successfully encoded {os.path.basename(path)} to {os.path.basename(cls_path)}")
+    csv_path = cls_path.replace("_cls.h5", f"_{dataset_name}_outputs.csv")
+    write_probs_csv(csv_path, res.probs, list(behaviors))
+    return cls_path, csv_path
 
 
 # ------------------------------------------------------------------------------------------------
@@ -409,13 +717,19 @@ def _csv_field(s: str) -> str:
     return s
 
 
-def write_probs_csv(path: str, probs: np.ndarray, behaviors: List[str]) -> None:
-    try:
-        import pandas as pd
-        pd.DataFrame(np.asarray(probs, dtype=np.float32), columns=behaviors).to_csv(path, index=False)
-    except ImportError:
-        with open(path, "w", newline="") as f:
-            f.write(format_probs_csv(probs, behaviors))
+def csv_header_line(behaviors: List[str]) -> str:
+    return ",".join(_csv_field(b) for b in behaviors) + "\n"
+
+
+def write_probs_csv(path: str, probs: np.ndarray, behaviors: List[str], threads: int = 1) -> None:
+    """``pd.DataFrame(probs, columns=behaviors).to_csv(path, index=False)`` (backend/cbas.py:565), byte for byte, through
+    the native formatter of the C ABI (cbas_csv_write_f32: ~1M rows/s per thread against pandas' 35k rows/s)."""
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    if probs.ndim != 2 or probs.shape[1] != len(behaviors):
+        raise ValueError(f"{len(behaviors)} column names for an array of shape {probs.shape}")
+    lib = _lib.load()
+    _lib.check(lib.cbas_csv_write_f32(os.fsencode(path), csv_header_line(behaviors).encode("utf-8"), probs.ctypes.data,
+                                      probs.shape[0], probs.shape[1], int(threads)), "cbas_csv_write_f32")
 
 
 _head_cache = {}       # single entry: id(module) -> (weakref to the module, parameter versions, device head)
@@ -444,6 +758,55 @@ def _as_mi355x_head(model, device) -> ClassifierLSTMDeltas:
     return _head_cache[key][2].to(device)
 
 
+INFER_CHUNK = 20000                  # backend/cbas.py:482: frames per read of the `cls` dataset
+
+
+def classify_cls_file(reader: "h5io.ClsReader", head: ClassifierLSTMDeltas, temperature: float, device,
+                      chunk: int = INFER_CHUNK) -> np.ndarray:
+    """The read + window loop of infer_file (backend/cbas.py:497-551): the `cls` dataset is read in ``chunk``-frame pieces
+    with a +-seq_len//2 halo of real rows (windows replicate a row only at the true ends of the clip, :512-525), the next
+    piece being read while the head works on the current one, so a day-long file needs a chunk of host memory, not the
+    whole clip.  Returns (N, C) float32 probabilities.  Any numeric dataset is accepted: IEEE half rows are consumed as
+    they are, everything else as float32 (the reference's ``.float()``, :507-508)."""
+    total, half = reader.shape[0], head.seq_len // 2
+    device = torch.device(device)
+    probs_dev = torch.empty((total, head.out_features), dtype=torch.float32, device=device)
+    spans = []
+    for start in range(0, total, chunk):
+        end = min(start + chunk, total)
+        spans.append((start, end, max(0, start - half), min(total, end + half)))
+
+    def read(k):
+        _s, _e, r0, r1 = spans[k]
+        a = reader.read(r0, r1)
+        t = torch.from_numpy(a)
+        return t.pin_memory() if device.type == "cuda" else t
+
+    box: dict = {}
+
+    def read_ahead(k):
+        try:
+            box[k] = read(k)
+        except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
+            box[k] = e
+
+    cur = read(0)
+    for k, (start, end, r0, r1) in enumerate(spans):
+        th = None
+        if k + 1 < len(spans):
+            th = threading.Thread(target=read_ahead, args=(k + 1,), name="cbas-cls-read", daemon=True)
+            th.start()
+        rows = cur.to(device, non_blocking=True)
+        # within this piece the windows clamp to [0, r1 - r0): that is the clip's edge exactly where a halo row is missing
+        head.infer_range_into(rows, r1 - r0, start - r0, end - start, probs_dev[r0:], temperature)
+        if th is not None:
+            th.join()
+            cur = box.pop(k + 1)
+            if isinstance(cur, BaseException):
+                raise cur
+    return probs_dev.cpu().numpy()
+
+
 def infer_file(file_path: str, model, dataset_name: str, behaviors: List[str], seq_len: int, device=None,
                temperature: float = 1.0) -> Optional[str]:
     output_file = file_path.replace("_cls.h5", f"_{dataset_name}_outputs.csv")
@@ -459,13 +822,9 @@ def infer_file(file_path: str, model, dataset_name: str, behaviors: List[str], s
             if total_frames == 0:
                 print(f"Warning: HDF5 file {file_path} is empty.")
                 return None
-            if r.itemsize != 2:
-                raise NotImplementedError("only float16 'cls' datasets (what encode_file writes) are supported")
             if r.shape[1] != head.in_features:
                 raise ValueError(f"'cls' has {r.shape[1]} features, the model expects {head.in_features}")
-            cls = r.read(0, total_frames)
-        cls_dev = torch.from_numpy(cls).to(device)
-        probs = head.infer_clip(cls_dev, temperature).cpu().numpy()
+            probs = classify_cls_file(r, head, temperature, device)
         if len(probs) != total_frames:
             print(f"Warning: Prediction count ({len(probs)}) != Frame count ({total_frames}).")
         if len(behaviors) != probs.shape[1]:

@@ -11,7 +11,7 @@ native; this class is the torch-tensor view of it.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -30,22 +30,28 @@ def _layout(frames, channel: int):
 
 
 class ClipStream:
-    def __init__(self, encoder: DinoEncoder, head: ClassifierLSTMDeltas, capacity: int,
+    """``head=None`` gives an encode-only session: the chunk loop of ``encode_file`` with the rows kept in HBM."""
+
+    def __init__(self, encoder: DinoEncoder, head: Optional[ClassifierLSTMDeltas], capacity: int,
                  temperature: float = 1.0, classify_every: int = 1024):
         self.enc, self.head = encoder, head
         self.capacity = int(capacity)
         self.temperature = float(temperature)
         self.classify_every = int(classify_every)
-        head.to(encoder.device)
-        head._ensure()
+        if head is not None:
+            head.to(encoder.device)
+            head._ensure()
         self._lib = _lib.load()
         self._keep = []              # frames of the open clip (device pushes must stay valid until finish)
         h = C.c_void_p()
         with torch.cuda.device(encoder.device):
-            _lib.check(self._lib.cbas_fused_create(encoder._h, head._h, self.capacity, self.temperature,
-                                                   self.classify_every, C.byref(h)), "cbas_fused_create")
+            _lib.check(self._lib.cbas_fused_create(encoder._h, head._h if head is not None else None, self.capacity,
+                                                   self.temperature, self.classify_every, C.byref(h)), "cbas_fused_create")
         self._h = h
         self.encoded = 0
+        # the native session drains through the encoder handle when it is destroyed: the encoder closes its open
+        # sessions before it frees that handle (DinoEncoder.close), whichever of the two is dropped first
+        encoder._register_session(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -86,14 +92,16 @@ class ClipStream:
         self.encoded += n
 
     def _views(self, p16, pp, n):
-        D, Cn = self.enc.config.hidden_size, self.head.out_features
+        D, Cn = self.enc.config.hidden_size, (self.head.out_features if self.head is not None else 0)
         dev = self.enc.device
+        session = self
 
         def view(ptr, rows, cols, dtype, itemsize):
-            if rows == 0:
-                return torch.empty((0, cols), dtype=dtype, device=dev)
+            if rows == 0 or cols == 0 or not ptr:
+                return torch.empty((rows if cols else 0, cols), dtype=dtype, device=dev)
             iface = {"shape": (rows, cols), "typestr": "<f%d" % itemsize, "data": (ptr, False), "version": 2}
-            holder = type("_Dev", (), {"__cuda_array_interface__": iface})()
+            # the tensor references the holder, the holder the session: the views keep the native buffers alive
+            holder = type("_Dev", (), {"__cuda_array_interface__": iface, "owner": session})()
             return torch.as_tensor(holder, device=dev)
         return view(p16.value, n, D, torch.float16, 2), view(pp.value, n, Cn, torch.float32, 4)
 
@@ -108,11 +116,11 @@ class ClipStream:
 
     def finish_host(self) -> Tuple[np.ndarray, np.ndarray]:
         """Classify the tail and copy the clip out: (cls_f16 (N,D) float16, probs (N,C) float32) numpy arrays."""
-        D, Cn = self.enc.config.hidden_size, self.head.out_features
+        D, Cn = self.enc.config.hidden_size, (self.head.out_features if self.head is not None else 0)
         o16 = np.empty((self.encoded, D), np.float16)
         opr = np.empty((self.encoded, Cn), np.float32)
         n = C.c_int64(0)
-        _lib.check(self._lib.cbas_fused_finish(self._h, o16.ctypes.data, opr.ctypes.data, None, None, C.byref(n), None),
-                   "cbas_fused_finish")
+        _lib.check(self._lib.cbas_fused_finish(self._h, o16.ctypes.data, opr.ctypes.data if Cn else None, None, None,
+                                               C.byref(n), None), "cbas_fused_finish")
         assert int(n.value) == self.encoded
         return o16, opr

@@ -51,7 +51,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   6
+#define CBAS_ABI_VERSION   7
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -165,6 +165,12 @@ int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int
                               int stop_layer, int stop_stage);
 int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes);
 
+/* Bring-up / tests: switch an implementation detail of the handle (never a result: every option's two settings are
+ * bit-identical, which is what the tests that use this prove).  Options:
+ *   "rope_lds"  1 (default): the q|k|v epilogue reads the RoPE angles, factorised by axis, from LDS; 0: from the [P][64]
+ *               table in global memory ([tf]:96-121, 168-200 either way). */
+int cbas_enc_debug_option(cbas_enc* h, const char* name, int value);
+
 /* Bring-up: time the fp16 GEMM kernel alone on random operands (GELU epilogue, M x N x K,
  * tile: 0 auto, 1 128x128, 2 256x128, 3 128x256, 4 256x256, 5+ experimental variants) and return a
  * position-weighted checksum of the fp16 output, so tile variants can be compared bit for bit. */
@@ -248,6 +254,12 @@ int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t
                               int64_t count, float temperature, float* probs_dev, float* logits_dev,
                               void* stream);
 
+/* The same over float32 rows: a `cls` dataset that is not IEEE half (the reference reads any dtype and converts with
+ * .float(), backend/cbas.py:507-508). */
+int cbas_head_infer_f32_range(cbas_head* h, const float* cls_f32_dev, int64_t n_frames, int64_t first,
+                              int64_t count, float temperature, float* probs_dev, float* logits_dev,
+                              void* stream);
+
 int cbas_head_get_config(const cbas_head* h, cbas_head_config* out);
 
 /* ---- fused streaming session: encode -> fp16 CLS -> head, rows never leave HBM ---------------------
@@ -259,7 +271,9 @@ int cbas_head_get_config(const cbas_head* h, cbas_head_config* out);
  * context has been encoded are classified (windows clamp at the clip's ends exactly as infer_file's
  * replicate padding does).  Results are identical to cbas_enc_forward_u8 + cbas_head_infer_f16 over the
  * whole clip, bit for bit.  The encoder and head handles must outlive the session and must not be driven
- * through their own asynchronous entry points while a clip is open. */
+ * through their own asynchronous entry points while a clip is open.
+ * `head` may be NULL: an encode-only session (the chunk loop of encode_file with the rows kept in HBM until the clip
+ * ends); probs_* outputs of cbas_fused_finish are then left untouched / NULL. */
 typedef struct cbas_fused cbas_fused;
 int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacity_frames, float temperature,
                       int64_t classify_every /* 0: 1024 */, cbas_fused** out);
@@ -318,6 +332,19 @@ int cbas_head_train_step(cbas_head_trainer* t, const float* x_dev, const int32_t
 int cbas_head_train_read(cbas_head_trainer* t, int32_t what, float* blob_host, int64_t n);
 /* Logits (n_windows, C) and latent (n_windows, 2h) of the LAST step's forward pass (device -> host). */
 int cbas_head_train_last_outputs(cbas_head_trainer* t, float* logits_host, float* latent_host, int32_t n_windows);
+
+/* ---- output text ---------------------------------------------------------------------------
+ * `<video>_<model>_outputs.csv` is written by the reference as
+ *   pd.DataFrame(np.array(all_probs), columns=behaviors).to_csv(output_file, index=False)    backend/cbas.py:565
+ * i.e. one header line, then per frame the float32 probabilities as numpy's str(np.float32): shortest decimal text that
+ * round-trips in float32, positional for 1e-4 <= |x| < 1e16 (else scientific with a signed, >= 2-digit exponent),
+ * NaN as an empty field, '\n' line ends.  These two calls produce exactly those bytes (host memory in, no GPU involved):
+ * cbas_csv_format_f32 formats n_rows x n_cols values into `out` and returns the byte count (with out = NULL: an upper
+ * bound for the buffer); cbas_csv_write_f32 writes `header_line` (already quoted, '\n'-terminated; may be NULL) and the
+ * rows to `path`, formatting on up to n_threads threads. */
+int64_t cbas_csv_format_f32(const float* values_host, int64_t n_rows, int32_t n_cols, char* out, int64_t cap);
+int cbas_csv_write_f32(const char* path, const char* header_line, const float* values_host, int64_t n_rows,
+                       int32_t n_cols, int32_t n_threads);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 

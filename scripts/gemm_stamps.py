@@ -2,11 +2,7 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbas_amd import _lib
-if os.environ.get("CBAS_EXP_LIB"):                     # an experiment build (scripts/build_exp.py)
-    import torch  # noqa: F401  (same HIP runtime as the product path)
-    lib = C.CDLL(os.environ["CBAS_EXP_LIB"])
-else:
-    lib = _lib.load()
+lib = _lib.load()
 fn = lib.cbas_debug_gemm_bench
 fn.restype = C.c_int
 fn.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]

@@ -26,10 +26,17 @@ print(f"host-streamed encode (RGB host frames, PCIe + staging included): {n/dt:.
 g = torch.from_numpy(frames[:64]).cuda()
 ref, _ = enc.encode_u8(g, want_f32=False); torch.cuda.synchronize()
 print("host-streamed == device-resident (bit-exact):", bool(np.array_equal(cls[:64], ref.cpu().numpy())))
-with tempfile.TemporaryDirectory() as td:
+with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
     vid = os.path.join(td, "clip.npy"); np.save(vid, frames)
     head = ClassifierLSTMDeltas(768, 9); head.load_state_dict(W.synth_head_weights(C.HeadConfig(), 4321)); head.to("cuda")
+    names = [f"b{i}" for i in range(9)]
     P.set_project_stamp("synthetic/vitb16")
-    t0 = time.perf_counter(); h5 = P.encode_file(enc, vid); t1 = time.perf_counter()
-    csv = P.infer_file(h5, head, "bench", [f"b{i}" for i in range(9)], 31, device="cuda"); t2 = time.perf_counter()
-    print(f"encode_file (.npy mmap -> _cls.h5): {n/(t1-t0):.0f} frames/s; infer_file (_cls.h5 -> CSV): {n/(t2-t1):.0f} frames/s; both: {n/(t2-t0):.0f} frames/s")
+    for rep in range(3):                                  # the first pass pays the page-locked ring, the session and the workspaces
+        t0 = time.perf_counter(); h5 = P.encode_file(enc, vid); t1 = time.perf_counter()
+        csv = P.infer_file(h5, head, "bench", names, 31, device="cuda"); t2 = time.perf_counter()
+        sep = (open(h5, "rb").read(), open(csv, "rb").read())
+        os.remove(h5); os.remove(csv)
+        t3 = time.perf_counter(); h5b, csvb = P.encode_infer_file(enc, head, vid, "bench", names); t4 = time.perf_counter()
+        same = sep == (open(h5b, "rb").read(), open(csvb, "rb").read())
+        print(f"pass {rep}: encode_file (.npy mmap -> _cls.h5) {n/(t1-t0):.0f} frames/s; infer_file (_cls.h5 -> CSV) {n/(t2-t1):.0f} frames/s; "
+              f"both in sequence {n/(t2-t0):.0f} frames/s; encode_infer_file (one pass, both files) {n/(t4-t3):.0f} frames/s; files identical: {same}")

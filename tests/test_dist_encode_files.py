@@ -56,11 +56,16 @@ class StubHead(ClassifierLSTMDeltas):
         return self
 
     def infer_clip(self, cls_f16, temperature=1.0, want_logits=False):
-        x = cls_f16.float()
-        n = x.shape[0]
-        idx = (torch.arange(n)[:, None] + torch.arange(-15, 16)[None, :]).clamp(0, n - 1)      # replicate-padded windows
-        win = x[idx].mean(1)
-        return torch.softmax(win[:, :C_] * 4.0 / max(1e-3, temperature), dim=1)
+        n = cls_f16.shape[0]
+        out = torch.empty((n, C_), dtype=torch.float32)
+        self.infer_range_into(cls_f16, n, 0, n, out, temperature)
+        return out
+
+    def infer_range_into(self, cls_rows, n_frames, first, count, probs_out, temperature=1.0):
+        x = cls_rows[:n_frames].float()
+        idx = (torch.arange(first, first + count)[:, None] + torch.arange(-15, 16)[None, :]).clamp(0, n_frames - 1)
+        win = x[idx].mean(1)                                                  # replicate-padded windows
+        probs_out[first:first + count] = torch.softmax(win[:, :C_] * 4.0 / max(1e-3, temperature), dim=1)
 
     def close(self):
         pass
@@ -154,3 +159,85 @@ def test_encode_files_matches_single_process_byte_for_byte(tmp_path, world):
             assert r["cls_file"] is None and r["csv_file"] is None
             assert not os.path.exists(os.path.splitext(r["path"])[0] + "_cls.h5")
     assert sum(r["frames"] for r in recs) == 40 + 700 + 33 + 513 + 90 + 17
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Scheduling properties ("what's weak" 3): rank 0 must not write on the critical path, and the clip -> rank
+# assignment must be a shared queue, not i mod N.  Measured with stand-ins of FIXED latency, so the arithmetic is exact.
+# ------------------------------------------------------------------------------------------------------------------
+class LatencyEncoder(StubEncoder):
+    """Takes `per_frame` seconds per frame, like a GPU that encodes at 1 / per_frame frames/s."""
+
+    def __init__(self, per_frame):
+        super().__init__()
+        self.per_frame = per_frame
+        self.max_batch = 64
+
+    def submit_host(self, slot, frames, channel=1):
+        import time
+        time.sleep(self.per_frame * frames.shape[0])
+        super().submit_host(slot, frames, channel)
+
+
+def _timed_worker(rank, world, port, td, q, per_frame, write_s):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    cdist.init_from_env("gloo")
+    if write_s:                                            # a slow disk under rank 0's writers
+        real = P.write_cls_file
+
+        def slow_write(*a, **k):
+            time.sleep(write_s)
+            return real(*a, **k)
+        P.write_cls_file = slow_write
+    paths = sorted(p for p in (os.path.join(td, f) for f in os.listdir(td)) if p.endswith(".npy"))
+    enc, head = LatencyEncoder(per_frame), StubHead()
+    dist.barrier()
+    t0 = time.perf_counter()
+    recs = cdist.encode_files(paths, enc, head=head, dataset_name="gold", behaviors=NAMES)
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        q.put((wall, recs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_timed(tmp_path, world, lengths, per_frame, write_s):
+    td = str(tmp_path)
+    rng = np.random.default_rng(3)
+    for i, n in enumerate(lengths):
+        np.save(os.path.join(td, f"clip{i:02d}.npy"), rng.integers(0, 200, (n, 8, 8, 3), dtype=np.uint8))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, td, q, per_frame, write_s)) for r in range(world)]
+    for p in procs:
+        p.start()
+    wall, recs = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r["status"] == "ok" and os.path.exists(r["cls_file"]) and os.path.exists(r["csv_file"]) for r in recs)
+    return wall, recs
+
+
+def test_world4_writes_are_off_the_critical_path(tmp_path):
+    """12 clips x 0.5 s of encode on 4 ranks, 0.1 s per `_cls.h5` write on rank 0.  Lock-step rounds with rank 0 writing
+    between them (the r2 design) take 3 x (0.5 + 4 x 0.1) = 2.7 s; with the writers beside the encode loop the job is
+    bounded by the encode time, 3 x 0.5 s, plus the last four clips' writes (0.4 s on the one HDF5 thread) = 1.9 s."""
+    wall, recs = _run_timed(tmp_path, 4, [500] * 12, per_frame=0.001, write_s=0.1)
+    print(f"world 4: 12 clips, encode 0.5 s each, write 0.1 s each: {wall:.2f} s (serial-writer rounds: 2.7 s)")
+    assert wall < 2.4
+    assert sorted(r["rank"] for r in recs) == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3
+
+
+def test_clips_come_from_a_shared_queue_not_round_robin(tmp_path):
+    """One 1.2 s clip and six 0.3 s clips on 3 ranks.  i mod 3 gives rank 0 the long clip plus two short ones (1.8 s);
+    with a shared queue the rank holding the long clip takes nothing else and the others share the rest (1.2 s)."""
+    wall, recs = _run_timed(tmp_path, 3, [1200, 300, 300, 300, 300, 300, 300], per_frame=0.001, write_s=0.0)
+    long_rank = recs[0]["rank"]
+    taken = [sum(1 for r in recs if r["rank"] == k) for k in range(3)]
+    print(f"world 3: long clip on rank {long_rank}, clips per rank {taken}, {wall:.2f} s (round-robin: 1.8 s)")
+    assert taken[long_rank] <= 2 and sum(taken) == 7
+    assert wall < 1.6

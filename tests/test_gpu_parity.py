@@ -240,8 +240,17 @@ def test_e2e_config1(golden_dir):
     assert r.max() < CLS_TOL + 5e-4          # includes the fp16 storage rounding (2^-11)
     probs = probs.cpu().numpy()
     # fp16 encoder (CLS within 1e-3) -> probabilities within 1e-2; labels identical outside near-ties
-    n_mis, n_near = assert_labels_match(probs, g["probs"], 1e-2)
-    assert n_mis <= max(1, n_near) and n_mis <= 2, (n_mis, n_near)
+    n_mis, n_near = assert_labels_match(probs, g["probs"], 1e-2)      # no flip outside the near-tie band (prints the band)
+    # Inside the band: identical labels cannot be promised by ANY arithmetic that is not bit-identical to the fp32 CPU
+    # path (the reference's own fp16-autocast GPU path included), so what is pinned is how narrow the exception is: at
+    # most one frame of this clip, and only where the reference's own top-2 margin is under 1e-2.
+    ref = g["probs"].astype(np.float64)
+    srt = np.sort(ref, axis=1)
+    flips = np.nonzero(probs.argmax(1) != ref.argmax(1))[0]
+    for f in flips:
+        print(f"[e2e_config1] frame {f}: reference top-2 margin {srt[f, -1] - srt[f, -2]:.3e}, |dp| there "
+              f"{np.abs(probs[f] - ref[f]).max():.3e}")
+    assert n_mis <= 1 and all(srt[f, -1] - srt[f, -2] < 1e-2 for f in flips), (n_mis, n_near)
     assert len(set(g["labels"].tolist())) >= 3            # the golden clip really changes behaviour
     # same fp16 rows in -> the fp32 head reproduces the reference labels exactly
     p_same = head.infer_clip(torch.from_numpy(g["cls_f16"]).cuda()).cpu().numpy()

@@ -476,11 +476,11 @@ def test_rope_table_in_lds_equals_global_table_and_the_oracle(hw):
     enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=4, max_frame=hw)
     try:
         a16, a32 = enc.encode_u8(torch.from_numpy(fr).cuda())
-        os.environ["CBAS_ROPE_LDS"] = "0"
+        enc.debug_option("rope_lds", 0)
         try:
             b16, b32 = enc.encode_u8(torch.from_numpy(fr).cuda())
         finally:
-            del os.environ["CBAS_ROPE_LDS"]
+            enc.debug_option("rope_lds", 1)
         torch.cuda.synchronize()
         assert torch.equal(a32, b32) and torch.equal(a16, b16)
         ref = PO.encode_frames(fr[:2], w, cfg, batch=2)

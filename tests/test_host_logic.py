@@ -194,3 +194,61 @@ def test_frame_sources(tmp_path):
     assert len(src) == 5 and np.array_equal(src.get_batch(range(1, 4)), fr[1:4])
     with pytest.raises(RuntimeError):
         P.open_video(str(tmp_path / "clip.mp4"))          # decord absent, no reader registered
+
+
+def test_cls_file_bytes_do_not_depend_on_the_append_granularity(tmp_path):
+    """encode_file appends 512 rows per chunk and flushes (backend/cbas.py:437-440); the multi-GPU writer and
+    encode_infer_file write a clip in one append.  Across several 8192-row HDF5 chunks the files are byte-identical."""
+    import hashlib
+    from cbas_amd import pipeline as P
+    rows = np.random.default_rng(0).standard_normal((20_000, 64)).astype(np.float16)
+    attrs = {"encoder_model_identifier": "facebook/dinov3-vitb16-pretrain-lvd1689m", "schema_version": "1.0"}
+    a = str(tmp_path / "chunked.h5")
+    with h5io.ClsWriter(a, 64, attrs) as w:
+        for i in range(0, rows.shape[0], 512):
+            w.append(rows[i:i + 512])
+            w.flush()
+    P.set_project_stamp(attrs["encoder_model_identifier"])
+    try:
+        b = P.write_cls_file(str(tmp_path / "video.mp4"), rows)
+    finally:
+        P.set_project_stamp(None)
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()      # noqa: E731
+    assert sha(a) == sha(b) and not os.path.exists(b + ".tmp")
+
+
+def test_cls_reader_hands_out_half_rows_as_they_are_and_anything_else_as_float32(tmp_path):
+    """The reference reads any `cls` dtype and converts with .float() (backend/cbas.py:507-508)."""
+    x = np.random.default_rng(1).standard_normal((300, 32))
+    for dt, want in (("f2", np.float16), ("f4", np.float32), ("f8", np.float32)):
+        p = str(tmp_path / f"{dt}.h5")
+        with h5io.ClsWriter(p, 32, {}, dtype=dt) as w:
+            w.append(x)
+        with h5io.ClsReader(p) as r:
+            got = r.read(17, 203)
+            assert r.is_half == (dt == "f2") and got.dtype == want and got.shape == (186, 32)
+            assert np.array_equal(got, x[17:203].astype(np.dtype(dt)).astype(want))
+
+
+def test_fp8_rows_are_stamped_as_such(tmp_path):
+    """MX-fp8 rows must be distinguishable on disk from fp16 rows."""
+    from cbas_amd import pipeline as P
+    from cbas_amd.encode_files import _needs_encoding
+    enc16 = type("E", (), {"precision": 0})()
+    enc8 = type("E", (), {"precision": 2})()
+    P.set_project_stamp("facebook/dinov3-vitb16-pretrain-lvd1689m")
+    try:
+        a16, a8 = P.file_attrs(enc16), P.file_attrs(enc8)
+    finally:
+        P.set_project_stamp(None)
+    assert a16 == {"encoder_model_identifier": "facebook/dinov3-vitb16-pretrain-lvd1689m", "schema_version": "1.0"}
+    assert a8["encoder_model_identifier"] == "facebook/dinov3-vitb16-pretrain-lvd1689m#mx-fp8" and a8["encoder_precision"] == "mx-fp8"
+    assert P.file_attrs(enc8) == {"encoder_precision": "mx-fp8"}                 # no project: still marked
+    rows = np.zeros((4, 16), np.float16)
+    v8 = str(tmp_path / "v8.mp4")
+    P.write_cls_file(v8, rows, a8)
+    with h5io.ClsReader(os.path.splitext(v8)[0] + "_cls.h5") as r:
+        assert r.attrs["encoder_precision"] == "mx-fp8"
+    # a project on the fp16 encoder re-encodes such a file; an fp8 run finds it up to date
+    assert _needs_encoding(v8, "facebook/dinov3-vitb16-pretrain-lvd1689m")
+    assert not _needs_encoding(v8, "facebook/dinov3-vitb16-pretrain-lvd1689m#mx-fp8")
