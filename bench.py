@@ -332,11 +332,35 @@ def main() -> None:
         enc.profile(False)
         enc.set_lanes(args.lanes)
 
+    # The files pass drives RCCL point-to-point transfers from a receiver thread (cbas_amd/dist.py).  No multi-GPU node
+    # has run that yet, so it gets a watchdog: if it has not come back in time, the line below is still printed (with the
+    # failure stated) and the ranks exit, instead of hanging the run that produced every other number in it.
     files = None
     if args.files > 0:
-        files = files_pass(args, enc, head, rank, world, device)
+        import threading
+        box: dict = {}
+
+        def _files():
+            try:
+                torch.cuda.set_device(device)
+                box["out"] = files_pass(args, enc, head, rank, world, device)
+            except BaseException as e:  # noqa: BLE001
+                box["err"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=_files, name="cbas-files-pass", daemon=True)
+        th.start()
+        th.join(float(os.environ.get("CBAS_FILES_PASS_TIMEOUT", "180")))
+        if th.is_alive():
+            files = {"error": "files_path pass did not finish within its time limit; skipped", "value": None}
+            hung = True
+        else:
+            files = box.get("out") if "err" not in box else {"error": box["err"], "value": None}
+            hung = False
+    else:
+        hung = False
 
     if rank != 0:
+        if hung:
+            os._exit(0)
         return
     frames_total = K * B * world
     hbm_value = frames_total / dt
@@ -406,6 +430,8 @@ def main() -> None:
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.model, args.hw, args.cpu_frames, 8)
     print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(0)
 
 
 if __name__ == "__main__":

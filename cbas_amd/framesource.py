@@ -257,3 +257,169 @@ class PipeFrameSource:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Motion-JPEG in an AVI container: the one COMPRESSED video format this image can decode end to end (Pillow ships
+# libjpeg-turbo; decord, ffmpeg, PyAV and OpenCV are all absent), so it is what exercises decode / copy / compute overlap
+# with real decoder work in the loop.  CBAS itself records H.264 .mp4 through ffmpeg (backend/cbas.py:732-734) and reads
+# it back with decord (:402); for those files the order in pipeline.open_video stays decord -> ffmpeg pipe.
+# ------------------------------------------------------------------------------------------------------------------
+def _riff_chunks(buf, start: int, end: int):
+    """(fourcc, data offset, size) of the chunks in buf[start:end]."""
+    import struct
+    p = start
+    while p + 8 <= end:
+        cc, size = buf[p:p + 4], struct.unpack_from("<I", buf, p + 4)[0]
+        yield bytes(cc), p + 8, size
+        p += 8 + size + (size & 1)
+
+
+class MJPEGAviSource:
+    """``decord.VideoReader``-shaped reader (``len``, ``get_batch(indices)`` -> (n, H, W, 3) uint8 RGB) for Motion-JPEG AVI
+    files.  The file is memory-mapped, the frame table comes from walking the ``movi`` list(s) once, and frames are decoded
+    by Pillow on a small thread pool (its JPEG decoder releases the GIL), straight into the caller's buffer when
+    ``read_into`` is used - which is what the decode-ahead thread of ``pipeline._ChunkStream`` does with its page-locked
+    ring buffers.  Decoded pixels are libjpeg-turbo's (ISLOW DCT, fancy upsampling); whether ffmpeg's MJPEG decoder +
+    swscale, which decord would use, produces the same green plane bit for bit is NOT verified in this environment."""
+
+    def __init__(self, path: str, threads: int = 8):
+        import mmap
+        self.path = path
+        self._f = open(path, "rb")
+        self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        mm = self._mm
+        if len(mm) < 12 or mm[0:4] != b"RIFF" or mm[8:12] != b"AVI ":
+            self.close()
+            raise ValueError(f"{path}: not a RIFF AVI file")
+        self._frames = []                        # (offset, size) of every video chunk, in order
+        self.width = self.height = 0
+        pos = 0
+        while pos + 12 <= len(mm) and mm[pos:pos + 4] == b"RIFF":           # 'AVI ' then OpenDML 'AVIX' segments
+            import struct
+            rsize = struct.unpack_from("<I", mm, pos + 4)[0]
+            rend = min(len(mm), pos + 8 + rsize)
+            for cc, off, size in _riff_chunks(mm, pos + 12, rend):
+                if cc != b"LIST":
+                    continue
+                kind = bytes(mm[off:off + 4])
+                if kind == b"hdrl":
+                    for c2, o2, s2 in _riff_chunks(mm, off + 4, off + size):
+                        if c2 == b"avih" and s2 >= 40:
+                            self.width, self.height = struct.unpack_from("<II", mm, o2 + 32)
+                        elif c2 == b"LIST" and bytes(mm[o2:o2 + 4]) == b"strl":
+                            for c3, o3, s3 in _riff_chunks(mm, o2 + 4, o2 + s2):
+                                if c3 == b"strh" and bytes(mm[o3:o3 + 4]) == b"vids":
+                                    codec = bytes(mm[o3 + 4:o3 + 8]).upper()
+                                    if codec not in (b"MJPG", b"JPEG", b"AVRN", b"LJPG"):
+                                        self.close()
+                                        raise ValueError(f"{path}: video stream is {codec!r}, not Motion-JPEG")
+                elif kind == b"movi":
+                    self._walk_movi(off + 4, off + size)
+            pos = rend + (rsize & 1)
+        if self._frames and not (self.width and self.height):
+            self.height, self.width = self._decode(0).shape[:2]
+        self.frame_shape = (self.height, self.width, 3)
+        self._threads = max(1, int(threads))
+        self._pool = None
+
+    def _walk_movi(self, start: int, end: int) -> None:
+        for cc, off, size in _riff_chunks(self._mm, start, end):
+            if cc == b"LIST" and bytes(self._mm[off:off + 4]) == b"rec ":
+                self._walk_movi(off + 4, off + size)
+            elif cc[2:4] in (b"dc", b"db") and cc[:2].isdigit():
+                self._frames.append((off, size))     # a zero-length chunk repeats the previous frame (AVI "dropped frame")
+
+    def __len__(self):
+        return len(self._frames)
+
+    def _decode(self, i: int) -> np.ndarray:
+        import io
+        from PIL import Image
+        while i > 0 and self._frames[i][1] == 0:
+            i -= 1
+        off, size = self._frames[i]
+        with Image.open(io.BytesIO(self._mm[off:off + size])) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def _executor(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix="cbas-mjpeg")
+        return self._pool
+
+    def read_into(self, start: int, stop: int, out: np.ndarray) -> None:
+        def one(k):
+            fr = self._decode(start + k)
+            if fr.shape != out.shape[1:]:
+                raise ValueError(f"{self.path}: frame {start + k} is {fr.shape}, the stream header says {out.shape[1:]}")
+            np.copyto(out[k], fr)
+        list(self._executor().map(one, range(stop - start)))
+
+    def get_batch(self, indices) -> np.ndarray:
+        idx = list(indices)
+        out = np.empty((len(idx),) + self.frame_shape, np.uint8)
+        if idx and idx == list(range(idx[0], idx[0] + len(idx))):
+            self.read_into(idx[0], idx[0] + len(idx), out)
+        else:
+            for k, i in enumerate(idx):
+                out[k] = self._decode(i)
+        return out
+
+    def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        for name in ("_mm", "_f"):
+            o = getattr(self, name, None)
+            if o is not None:
+                try:
+                    o.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                setattr(self, name, None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def write_mjpeg_avi(path: str, frames: np.ndarray, fps: int = 10, quality: int = 90) -> None:
+    """Write uint8 (N, H, W, 3) RGB (or (N, H, W) grey) frames as a Motion-JPEG AVI (one stream, ``idx1`` index): test and
+    benchmark clips that any player / ffmpeg / decord opens.  JPEG is lossy: the decoded frames are the reference point,
+    not ``frames``."""
+    import io
+    import struct
+    from PIL import Image
+    frames = np.asarray(frames, np.uint8)
+    n, h, w = frames.shape[:3]
+    jpegs = []
+    for i in range(n):
+        b = io.BytesIO()
+        Image.fromarray(frames[i]).save(b, format="JPEG", quality=quality, subsampling=0 if frames.ndim == 4 else None)
+        jpegs.append(b.getvalue())
+
+    def chunk(cc: bytes, data: bytes) -> bytes:
+        return cc + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+
+    def lst(kind: bytes, data: bytes) -> bytes:
+        return b"LIST" + struct.pack("<I", len(data) + 4) + kind + data
+
+    biggest = max((len(j) for j in jpegs), default=0)
+    avih = struct.pack("<14I", 1_000_000 // max(1, fps), biggest * fps, 0, 0x10, n, 0, 1, biggest, w, h, 0, 0, 0, 0)
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII", 0, 0, 0, 0, 1, fps, 0, n, biggest, 0xFFFFFFFF, 0) + struct.pack("<4h", 0, 0, w, h)
+    strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi_body, idx, off = b"", b"", 4
+    parts = []
+    for j in jpegs:
+        c = chunk(b"00dc", j)
+        idx += b"00dc" + struct.pack("<III", 0x10, off, len(j))
+        off += len(c)
+        parts.append(c)
+    movi_body = b"".join(parts)
+    body = b"AVI " + hdrl + lst(b"movi", movi_body) + chunk(b"idx1", idx)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib, h5io
 from .encoder import DinoEncoder
-from .framesource import PipeFrameSource, Y4MFileSource
+from .framesource import MJPEGAviSource, PipeFrameSource, Y4MFileSource
 from .head import ClassifierLSTMDeltas, from_reference_module
 
 CHUNK_SIZE = 512                     # backend/cbas.py:48
@@ -109,17 +109,64 @@ def register_reader(ext: str, factory: Callable[[str], object]) -> None:
     _READERS[ext.lower()] = factory
 
 
+_source_check_done = False
+
+
+def _cross_check_sources(path: str, reader) -> None:
+    """Once per process, when BOTH decoders exist: the first frames' green plane from decord (what the reference consumes,
+    backend/cbas.py:425,431) against the ffmpeg pipe's ``extractplanes=g`` plane (what this package falls back to when
+    decord is missing).  The two go through different pixel-format conversions (decord: swscale to RGB24, then [:, :, 1];
+    the pipe: the filter graph's own conversion to a planar-RGB format), and no environment this package was built in had
+    either decoder, so their equality is UNVERIFIED: this check is what finds out, on the first video a real install opens.
+    It never fails the encode; a mismatch is reported loudly because embeddings made through the two sources would differ."""
+    global _source_check_done
+    if _source_check_done or os.environ.get("CBAS_VERIFY_FRAME_SOURCE") == "0":
+        return
+    _source_check_done = True
+    pipe = None
+    try:
+        n = min(16, len(reader))
+        if n == 0:
+            return
+        a = np.asarray(reader.get_batch(range(n)))[:, :, :, 1]
+        pipe = PipeFrameSource(path, prefetch_frames=n, n_frames=len(reader))
+        b = np.asarray(pipe.get_batch(range(n)))
+        if a.shape != b.shape:
+            print(f"WARNING: cbas_amd frame-source check on {os.path.basename(path)}: decord frames are {a.shape[1:]}, the ffmpeg "
+                  f"pipe delivers {b.shape[1:]}")
+        elif not np.array_equal(a, b):
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            print(f"WARNING: cbas_amd frame-source check on {os.path.basename(path)}: the ffmpeg pipe's green plane differs from "
+                  f"decord's on {float((d > 0).mean()) * 100:.2f} % of the pixels of the first {n} frames (max |diff| {int(d.max())}); "
+                  "embeddings made without decord will not match the reference's bit for bit")
+        else:
+            print(f"cbas_amd frame-source check: ffmpeg-pipe green plane == decord green plane on the first {n} frames")
+    except Exception as e:  # noqa: BLE001 - a diagnostic must never break the encode
+        print(f"cbas_amd frame-source check skipped: {e}")
+    finally:
+        if pipe is not None:
+            pipe.close()
+
+
 def open_video(path: str):
     ext = os.path.splitext(path)[1].lower()
     if ext in _READERS:
         return _READERS[ext](path)
     try:
-        return _DecordSource(path)
+        r = _DecordSource(path)
     except ImportError as e:
+        if ext == ".avi":                            # Motion-JPEG AVI decodes in-process (Pillow); anything else falls through
+            try:
+                return MJPEGAviSource(path)
+            except ValueError:
+                pass
         if shutil.which("ffmpeg") and shutil.which("ffprobe"):
             return PipeFrameSource(path)            # decoder process + reader thread (cbas_amd/framesource.py)
         raise RuntimeError(f"no frame source for {path!r}: decord is not installed, ffmpeg/ffprobe are not on PATH and "
                            f"no reader is registered for {ext!r}") from e
+    if shutil.which("ffmpeg") and shutil.which("ffprobe"):
+        _cross_check_sources(path, r)
+    return r
 
 
 # ------------------------------------------------------------------------------------------------

@@ -135,3 +135,82 @@ def test_decode_ahead_overlaps_and_preserves_order_and_errors():
         for i, end, fr in P._chunks(bad, len(bad)):
             got.append(i)
     assert got == [0, 512]
+
+
+def test_mjpeg_avi_round_trip_and_decode_ahead(tmp_path):
+    """A real compressed video through the reader interface encode_file uses: Motion-JPEG AVI written here, decoded by
+    Pillow's libjpeg-turbo.  Frame count, shape, random and sequential access, read_into == get_batch, dropped-frame
+    chunks, and the decode-ahead stream delivers exactly the reader's frames."""
+    from cbas_amd import framesource as F, pipeline as P, synth
+    fr = synth.cage_frames(2, 70, 48, 64)
+    p = str(tmp_path / "clip.avi")
+    F.write_mjpeg_avi(p, fr, fps=10, quality=95)
+    r = P.open_video(p)                                      # no decord here -> the in-process MJPEG reader
+    assert isinstance(r, F.MJPEGAviSource) and len(r) == 70 and r.frame_shape == (48, 64, 3)
+    allf = r.get_batch(range(70))
+    assert allf.shape == (70, 48, 64, 3) and allf.dtype == np.uint8
+    assert np.abs(allf.astype(int) - fr.astype(int)).mean() < 6.0          # lossy, but the same pictures
+    assert np.array_equal(r.get_batch([3, 69, 0]), allf[[3, 69, 0]])
+    out = np.empty((20, 48, 64, 3), np.uint8)
+    r.read_into(10, 30, out)
+    assert np.array_equal(out, allf[10:30])
+    got = [f.copy() for _i, _e, f in P._chunks(r, len(r), piece=32)]
+    assert [g.shape[0] for g in got] == [32, 32, 6] and np.array_equal(np.concatenate(got), allf)
+    r.close()
+    # decoding is deterministic (same bytes -> same pixels), so embeddings of a file are reproducible
+    r2 = F.MJPEGAviSource(p, threads=1)
+    assert np.array_equal(r2.get_batch(range(70)), allf)
+    r2.close()
+    # not Motion-JPEG -> refused (open_video then goes on to the ffmpeg pipe, or reports that nothing can read it)
+    raw = bytearray(open(p, "rb").read())
+    i = raw.find(b"vidsMJPG")
+    raw[i + 4:i + 8] = b"H264"
+    bad = str(tmp_path / "h264.avi")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="not Motion-JPEG"):
+        F.MJPEGAviSource(bad)
+    with pytest.raises(RuntimeError, match="no frame source"):
+        P.open_video(bad)
+
+
+def test_decord_vs_ffmpeg_green_plane_cross_check(tmp_path, monkeypatch, capsys):
+    """When both decoders exist the first frames are compared once and a mismatch is reported; with fakes,
+    since neither decoder exists in this image."""
+    import shutil as _sh
+    from cbas_amd import pipeline as P
+    frames = np.random.default_rng(0).integers(0, 256, (20, 8, 8, 3), dtype=np.uint8)
+
+    class FakeDecord:
+        def __init__(self, path):
+            pass
+
+        def __len__(self):
+            return 20
+
+        def get_batch(self, idx):
+            return frames[list(idx)]
+
+    class FakePipe:
+        delta = 0
+
+        def __init__(self, path, prefetch_frames=512, n_frames=None):
+            pass
+
+        def get_batch(self, idx):
+            return (frames[list(idx), :, :, 1].astype(np.int16) + self.delta).clip(0, 255).astype(np.uint8)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(P, "_DecordSource", FakeDecord)
+    monkeypatch.setattr(P, "PipeFrameSource", FakePipe)
+    monkeypatch.setattr(_sh, "which", lambda name: "/usr/bin/" + name)
+    monkeypatch.setattr(P, "_source_check_done", False)
+    assert isinstance(P.open_video(str(tmp_path / "a.mp4")), FakeDecord)
+    assert "== decord green plane" in capsys.readouterr().out
+    P.open_video(str(tmp_path / "b.mp4"))
+    assert capsys.readouterr().out == ""                      # once per process
+    monkeypatch.setattr(P, "_source_check_done", False)
+    FakePipe.delta = 1
+    P.open_video(str(tmp_path / "c.mp4"))
+    assert "WARNING" in capsys.readouterr().out and "differs from" not in capsys.readouterr().out

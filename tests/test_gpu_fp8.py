@@ -7,7 +7,9 @@ argmax-label parity (outside the near-tie band its own probability error implies
   2. the quantiser: e4m3 bytes and E8M0 scales equal the CPU restatement (oracle/mx_oracle.py) bit for bit;
   3. the encoder: CLS vs the CPU restatement of the same quantised arithmetic, and vs the fp32 reference golden - the
      tolerance it actually achieves is printed and asserted;
-  4. labels: fp8 clip -> head vs the fp16 path (itself pinned to the reference), flips counted and printed.
+  4. labels: through heads TRAINED on the device on labelled synthetic clips - the fp8 pipeline (fp8 rows + a head trained on
+     fp8 rows) must classify held-out clips within 0.10 of the fp16 pipeline's accuracy; the agreement of an fp16-trained
+     head fed fp8 rows (70-80 %) is printed: the two kinds of rows are not interchangeable, which is why fp8 files are stamped.
 """
 import ctypes as C_
 import os
@@ -107,63 +109,32 @@ def test_fp8_encoder_against_its_restatement_and_the_reference(golden_dir, cfgna
     assert r_ref < 1.5 * r_emu_ref + 1e-2      # and no worse than the stated arithmetic implies
 
 
-def test_fp8_labels_against_the_fp16_path():
-    """A 1 024-frame clip with temporal structure through encoder (fp8 vs fp16) -> fp16 rows -> head: probabilities
-    within the error the CLS perturbation implies and no label flip outside the near-tie band; counts printed."""
-    from cbas_amd.encoder import DinoEncoder
-    from cbas_amd.head import ClassifierLSTMDeltas
-    cfg = C.VIT_B16
-    w = W.synth_encoder_weights(cfg, 1234)
-    head = ClassifierLSTMDeltas(768, 9)
-    head.load_state_dict(W.synth_head_weights(C.HeadConfig(), 4321))
-    head.to("cuda")
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(11)
-    N = 1024
-    base = torch.randint(0, 256, (6, 224, 224), dtype=torch.uint8, device="cuda", generator=gen).float()
-    idx = torch.arange(N, device="cuda")
-    seg, frac = (idx // 200) % 6, ((idx % 200).float() / 200.0)
-    clip = (base[seg] * (1 - frac[:, None, None]) + base[(seg + 1) % 6] * frac[:, None, None]).clamp(0, 255).to(torch.uint8)
-    probs = {}
-    for prec in (0, 2):
-        enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=64, max_frame=(224, 224), precision=prec)
-        c16, _ = enc.encode_u8(clip, want_f32=False)
-        probs[prec] = head.infer_clip(c16, 1.0).cpu().numpy()
-        cls = c16.float().cpu().numpy()
-        if prec == 0:
-            cls0, c16_0 = cls, c16.clone()
-        enc.close()
-    # calibration: white noise of the SAME per-row norm as the fp8 error, added to the fp16 rows, through the same head
-    err = torch.from_numpy(np.linalg.norm(cls - cls0, axis=1)).to("cuda")
-    noise = torch.randn(c16_0.shape, device="cuda", generator=gen)
-    noise = noise / noise.norm(dim=1, keepdim=True) * err[:, None]
-    probs["noise"] = head.infer_clip((c16_0.float() + noise).half(), 1.0).cpu().numpy()
-    head.close()
-    rel = (np.linalg.norm(cls - cls0, axis=1) / np.linalg.norm(cls0, axis=1)).max()
-    adp = np.abs(probs[2] - probs[0]).max(1)
-    adp_n = np.abs(probs["noise"] - probs[0]).max(1)
-    agree = float((probs[2].argmax(1) == probs[0].argmax(1)).mean())
-    agree_n = float((probs["noise"].argmax(1) == probs[0].argmax(1)).mean())
-    s0 = np.sort(probs[0], axis=1)
-    margin = s0[:, -1] - s0[:, -2]
-    flips = probs[2].argmax(1) != probs[0].argmax(1)
-    print(f"\nfp8 vs fp16 on a {N}-frame clip (synthetic weights): CLS rel err max {rel:.3e}; |dp| median {np.median(adp):.3e} "
-          f"p99 {np.quantile(adp, 0.99):.3e} max {adp.max():.3e}; label agreement {agree:.4f} ({int(flips.sum())} flips); "
-          f"fp16 top-2 margin at the flips: median {np.median(margin[flips]) if flips.any() else 0:.3e} max "
-          f"{margin[flips].max() if flips.any() else 0:.3e}\n"
-          f"white noise of the same per-row norm on the fp16 rows: |dp| median {np.median(adp_n):.3e}; label agreement {agree_n:.4f}")
-    # The label bar, stated exactly.  With SYNTHETIC weights the head is hypersensitive: a random BiLSTM over time
-    # differences of the CLS rows of a random ViT turns a 6 % row perturbation into |dp| ~ 0.5, so "no flip outside
-    # the near-tie band" is weak by construction (the band is almost the whole simplex) and the raw agreement moves by
-    # +-0.1 with ANY rounding-level change upstream (it read 0.84 and 0.73 for two GELU formulations 3e-7 apart).
-    # What can be asserted is relative: the fp8 error flips about as many labels as white noise of the same size does
-    # (measured: 0.73 - 0.84 for fp8 against 0.86 for the noise; the fp8 error is correlated along the row, white
-    # noise is not).
-    # Real checkpoints cannot be fetched here (gated, no network).
-    n_mis, n_near = assert_labels_match(probs[2], probs[0], prob_tol=1.0)
-    assert agree > agree_n - 0.2, (agree, agree_n)
-    assert np.median(adp) < 2.5 * np.median(adp_n) + 1e-3
-    assert rel < 1.2e-1
+def test_fp8_label_gate_through_a_head_trained_on_the_device(capsys):
+    """The label bar of the MX-fp8 throughput mode (BASELINE.json configs[4]; reference low-precision site:
+    backend/cbas.py:433-434), measured through heads TRAINED on the device (cbas_head_train_*) on labelled synthetic clips
+    (scripts/fp8_label_study.py): 6 behaviours = scene texture + blob motion, 7 200 training windows, 3 072 held-out frames.
+
+    What is asserted, and why it is this and not "labels identical to the fp16 path":
+    * MX-fp8 rows are ~6e-2 from the fp16 rows on unstructured (synthetic) weights: every fp8 GEMM adds ~2-3 % relative
+      noise to its output (3 mantissa bits; the block scales only fix the range).  A head trained on fp16 rows therefore
+      agrees with itself on only 70-80 % of the held-out frames when fed fp8 rows, with flips at fp16 margins up to 0.9 - this
+      is measured here and PRINTED, and it is why fp8 files are stamped as a different encoder (pipeline.file_attrs) and a
+      bundle trained on fp16 rows is refused for an fp8 run (encode_files.py): the two kinds of rows are not interchangeable.
+    * Used as what it is - a different encoder, with a head trained on ITS rows - the mode must classify held-out clips
+      nearly as well as the fp16 pipeline does: accuracy against the TRUE labels within 0.10 of the fp16 pipeline's and
+      far above chance (1/6), bit-reproducibly.  A kernel that corrupted, dropped or mis-scaled rows fails this."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fp8_label_study as S
+    with capsys.disabled():
+        res = S.study("vitb16", 224, n_classes=6, epochs=30, plans=(2,), verbose=True)
+    r = res["plans"]["2"]
+    assert res["fp16_accuracy"] > 0.85                                   # the task is learnable from fp16 rows
+    assert r["own_head_bit_reproducible"]
+    assert r["own_head_accuracy"] > 0.70 and r["own_head_accuracy"] > res["fp16_accuracy"] - 0.10, r
+    assert r["accuracy"] > 0.5                                           # even the mismatched pairing is far from chance
+    assert 4e-2 < r["cls_rel_err_max"] < 1.0e-1                          # the format's error, neither better nor worse
+    assert r["flips_outside_near_tie_band"] == 0                         # (the band is wide here: printed above)
 
 
 def test_fp8_rejects_unsupported_shapes():

@@ -209,3 +209,35 @@ def test_encode_files_world1_never_writes_on_the_encode_thread(tmp_path, monkeyp
     finally:
         head.close()
         enc.close()
+
+
+def test_encode_file_on_a_compressed_video_equals_its_decoded_frames(tmp_path):
+    """Motion-JPEG AVI (real decoder work on the decode-ahead thread, frames landing in the page-locked ring) against the same
+    decoded frames stored as .npy: identical `_cls.h5` rows and identical probabilities."""
+    from cbas_amd import framesource as F, h5io, pipeline as P
+    cfg, enc, head = _tiny()
+    try:
+        fr = synth.cage_frames(12, 300, 64, 64)
+        avi = str(tmp_path / "rec.avi")
+        F.write_mjpeg_avi(avi, fr, quality=90)
+        with F.MJPEGAviSource(avi) if hasattr(F.MJPEGAviSource, "__enter__") else _closing(F.MJPEGAviSource(avi)) as r:
+            dec = r.get_batch(range(len(r)))
+        assert dec.shape == fr.shape and not np.array_equal(dec, fr)          # lossy: the decoded frames are the reference point
+        np.save(str(tmp_path / "dec.npy"), dec)
+        a = P.encode_file(enc, avi)
+        b = P.encode_file(enc, str(tmp_path / "dec.npy"))
+        assert os.path.basename(a) == "rec_cls.h5"
+        with h5io.ClsReader(a) as ra, h5io.ClsReader(b) as rb:
+            assert ra.shape == (300, cfg.hidden_size)
+            assert np.array_equal(ra.read(0, 300).view(np.uint16), rb.read(0, 300).view(np.uint16))
+        h5c, csvc = P.encode_infer_file(enc, head, avi, "m", list("abcde"))
+        csvd = P.infer_file(b, head, "m", list("abcde"), 31, device="cuda")
+        assert _sha(csvc) == _sha(csvd)
+    finally:
+        head.close()
+        enc.close()
+
+
+def _closing(obj):
+    import contextlib
+    return contextlib.closing(obj)
