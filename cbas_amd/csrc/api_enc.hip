@@ -37,6 +37,10 @@ struct LayerW {
     // precision 2: MX-fp8 copies (e4m3 bytes, same [N][K] layout) + E8M0 block scales [K/128][N] dwords
     uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *wup8 = nullptr, *wdown8 = nullptr;
     uint32_t *sqkv = nullptr, *so = nullptr, *sup = nullptr, *sdown = nullptr;
+    // LayerNorm fold (precision 0): fp16(gamma o W) of the two GEMMs that consume a LayerNorm output, the column sums of
+    // those rounded weights and the folded biases beta W^T + b
+    f16 *wqkv_f = nullptr, *wup_f = nullptr;
+    float *qkv_cs = nullptr, *qkv_bf = nullptr, *up_cs = nullptr, *up_bf = nullptr;
 };
 
 struct Slot {
@@ -92,6 +96,14 @@ struct cbas_enc {
     f16* cls16 = nullptr;
     bool prune_last = true;
     bool rope_in_lds = true;           // cbas_enc_debug_option("rope_lds"): q|k|v epilogue reads the by-axis RoPE table from LDS
+    // LayerNorm fold: see run_blocks.  fold_ok = the folded weights exist; ln_fold = use them (debug option "ln_fold").
+    // Off by default: with two batches in flight it measured +0 ... +1 % (the LayerNorm kernels already hide under the other
+    // lane's GEMMs, the fold moves their work into epilogues that do not); -5.4 % of kernel time with one batch in flight.
+    bool fold_ok = false, ln_fold = false;
+    f16* w16_fold = nullptr;
+    float* fold_vec = nullptr;
+    f16* x16 = nullptr;                // [rows_cap][D] fp16 copy of the residual stream (the folded GEMMs' A operand)
+    float2* lnst = nullptr;            // [4][rows_cap] per-row LayerNorm statistics by 256-column block
     int last_rows = 0;
     hipStream_t compute = nullptr, copy = nullptr;
     Slot slots[CBAS_ENC_SLOTS];
@@ -100,7 +112,7 @@ struct cbas_enc {
     // compute lanes, each a full workspace + its own stream, so that one batch's partial tile rounds,
     // LayerNorm and attention run under the other batch's GEMMs (+10 % measured; outputs bit-identical).
     // lane 0 = the buffers above on `compute`; the synchronous cbas_enc_forward_* always use lane 0.
-    struct Lane { f16 *A_patch, *h16, *qkv16, *u16, *cls16; float* x; uint32_t *sc_h, *sc_u; hipStream_t stream; };
+    struct Lane { f16 *A_patch, *h16, *qkv16, *u16, *cls16; float* x; uint32_t *sc_h, *sc_u; hipStream_t stream; f16* x16; float2* lnst; };
     Lane lanes[2] = {};
     int n_lanes = 1;
     uint64_t submit_count = 0;
@@ -311,7 +323,7 @@ struct ProfScope {
 // Last transformer layer when only the CLS rows are consumed.  K and V are still projected for every row
 // (the CLS query attends to all tokens); the query, attention, o_proj, LayerNorm 2 and the MLP run on the n CLS
 // rows, read and written in place in the residual stream with a row stride of T*D.
-int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t st) {
+int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t st, bool fold) {
     const int D = h->D, F = h->F, M = n * T, M_pad = (int)round_up(M, 128);
     const int64_t cap = round_up(h->cfg.max_batch, 128);
     f16* qc = h->cls16;                     // [n][D] CLS queries (bias added, scaled by 1/8; no RoPE on prefix rows)
@@ -327,16 +339,24 @@ int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t s
         { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, (int64_t)T * D, w.ln1_w, w.ln1_b, hc, n, D, h->cfg.layer_norm_eps, st)); }
         kv.A8 = (const uint8_t*)h->h16; kv.A_sc = h->sc_h; kv.sc_lda = sc_ld;
         kv.W8 = w.wqkv8 + (size_t)D * D; kv.W_sc = w.sqkv + D; kv.sc_ldw = 3 * D;
+    } else if (fold) {
+        // LayerNorm fold: the k | v rows of the folded weight on the raw fp16 residual stream; the n CLS rows' LayerNorm 1
+        // (for the query) is computed on its own, into the LN2 slot for now
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, (int64_t)T * D, w.ln1_w, w.ln1_b, hc, n, D, h->cfg.layer_norm_eps, st)); }
+        kv.A = h->x16; kv.W = w.wqkv_f + (size_t)D * D;
+        kv.tile = (long)((M + 255) / 256) * (2 * D / 256) >= 120 ? GEMM_TILE_PP_AUTO : GEMM_TILE_PP_128x256;
+        kv.ln_in = h->lnst; kv.ln_colsum = w.qkv_cs + D; kv.ln_parts = D / 256; kv.ln_ld = (int)h->rows_cap; kv.ln_eps = h->cfg.layer_norm_eps;
     } else {
         { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
         kv.A = h->h16; kv.W = w.wqkv + (size_t)D * D; kv.W_lo = split ? w.wqkv_lo + (size_t)D * D : nullptr;
     }
-    kv.M = M; kv.M_pad = M_pad; kv.N = 2 * D; kv.K = D; kv.bias = w.qkv_b + D; kv.out_f16 = h->qkv16 + D; kv.ldo = 3 * D;
+    kv.M = M; kv.M_pad = M_pad; kv.N = 2 * D; kv.K = D; kv.bias = (fold ? w.qkv_bf : w.qkv_b) + D; kv.out_f16 = h->qkv16 + D; kv.ldo = 3 * D;
     kv.tokens_per_frame = T; kv.n_prefix = h->NP; kv.D = D; kv.sec0 = 1;
     set_rope(h, kv);
-    { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, kv, st)); }
-    GemmParams q{};                         // q section, CLS rows only (row b*T of h16; the compact fp16 rows when f8)
-    q.A = f8 ? hc : h->h16; q.lda = f8 ? D : T * D; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr;
+    { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm(fold ? EPI_QKV_LN : EPI_QKV, kv, st)); }
+    const bool compact_q = f8 || fold;      // the CLS rows' LayerNorm 1 sits in hc
+    GemmParams q{};                         // q section, CLS rows only (row b*T of h16; the compact fp16 rows when f8 / folded)
+    q.A = compact_q ? hc : h->h16; q.lda = compact_q ? D : T * D; q.W = w.wqkv; q.W_lo = split ? w.wqkv_lo : nullptr;
     q.M = n; q.M_pad = n; q.N = D; q.K = D; q.bias = w.qkv_b; q.out_f16 = qc; q.ldo = D;
     q.tokens_per_frame = 1; q.n_prefix = 1; q.D = D; q.sec0 = 0;      // every row is token 0: no RoPE
     { PROF(CBAS_PROF_QKV, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_QKV, q, st)); }
@@ -383,6 +403,17 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     // done for n rows instead of n*T (rows are independent: bit-identical CLS).  Debug taps run it in full.
     const bool prune = h->prune_last && stop_layer < 0 && (cls_f32 || cls_f16);
     const bool split = h->cfg.precision == 1, f8 = h->cfg.precision == 2;
+    // LayerNorm fold.  LN(x) W^T + b = rstd (x (gamma o W)^T - mean colsum(gamma o W)) + (beta W^T + b): the two GEMMs that
+    // consume a LayerNorm output ([tf]:404-445: q|k|v after norm1, up_proj after norm2) run on the raw fp16 residual stream
+    // with gamma folded into their weights and apply mean / rstd in their epilogues; the two GEMMs that produce the residual
+    // stream (o_proj, down_proj) write that fp16 copy and the row statistics in theirs.  22 of the 24 LayerNorm launches
+    // of a ViT-B step and their 114 MB per layer of traffic disappear.  The fold lives in the ping-pong kernel only, so in this
+    // mode all four GEMMs run there at EVERY batch size (128-row tiles for small problems, as precision 2 does): a frame's
+    // CLS row must not depend on how many frames shared its batch.  Debug taps and precision 1 / 2 keep the LayerNorm kernels.
+    const bool fold = h->ln_fold && h->fold_ok && stop_layer < 0;
+    const int ln_ld = (int)h->rows_cap;
+    auto pp_tile = [&](int N) { return (long)((M + 255) / 256) * (N / 256) >= 120 ? GEMM_TILE_PP_AUTO : GEMM_TILE_PP_128x256; };
+    if (fold) { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_ln_stats_x16(h->x, h->x16, h->lnst, ln_ld, M, D, st)); }
     if (f8 && stop_layer >= 0) return cbas_fail(CBAS_EINVAL, "debug taps read fp16 buffers; not available with precision 2");
     const int sc_ld = (int)h->rows_cap;
     uint8_t* const h8 = reinterpret_cast<uint8_t*>(h->h16);      // fp8 activations live in the fp16 buffers' memory
@@ -391,9 +422,41 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
         const LayerW& w = h->layers[l];
         auto stop = [&](int stage) { return stop_layer == l && stop_stage == stage; };
         if (prune && l == h->L - 1) {
-            rc = run_last_layer_cls(h, w, n, T, st);
+            rc = run_last_layer_cls(h, w, n, T, st, fold);
             if (rc) return rc;
             break;
+        }
+        if (fold) {
+            auto ln_consumer = [&](GemmParams& g, const float* colsum) {
+                g.ln_in = h->lnst; g.ln_colsum = colsum; g.ln_parts = D / 256; g.ln_ld = ln_ld; g.ln_eps = h->cfg.layer_norm_eps;
+            };
+            auto ln_producer = [&](GemmParams& g) { g.x16_out = h->x16; g.ln_out = h->lnst; g.ln_ld = ln_ld; };
+            const bool more = l + 1 < h->L;             // the last layer's down_proj feeds the final norm only
+            GemmParams q{};
+            q.tile = pp_tile(3 * D);
+            q.A = h->x16; q.W = w.wqkv_f; q.M = M; q.M_pad = M_pad; q.N = 3 * D; q.K = D; q.bias = w.qkv_bf; q.out_f16 = h->qkv16; q.ldo = 3 * D;
+            q.tokens_per_frame = T; q.n_prefix = h->NP; q.D = D;
+            ln_consumer(q, w.qkv_cs);
+            set_rope(h, q);
+            { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm(EPI_QKV_LN, q, st)); }
+            { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D);
+              LAUNCH_TRY(launch_attention(h->qkv16, nullptr, h->h16, nullptr, sc_ld, n, T, D, h->NH, st)); }
+            GemmParams o{};
+            o.tile = pp_tile(D);
+            o.A = h->h16; o.W = w.wo; o.M = M; o.M_pad = M_pad; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out_f32 = h->x; o.ldo = D;
+            ln_producer(o);
+            { PROF(CBAS_PROF_OPROJ, 2.0 * M * (double)D * D); LAUNCH_TRY(launch_gemm(EPI_RESID_LN, o, st)); }
+            GemmParams u{};
+            u.tile = pp_tile(F);
+            u.A = h->x16; u.W = w.wup_f; u.out_f16 = h->u16; u.M = M; u.M_pad = M_pad; u.N = F; u.K = D; u.bias = w.up_bf; u.ldo = F;
+            ln_consumer(u, w.up_cs);
+            { PROF(CBAS_PROF_UP, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(EPI_GELU_LN, u, st)); }
+            GemmParams d{};
+            d.tile = pp_tile(D);
+            d.A = h->u16; d.W = w.wdown; d.M = M; d.M_pad = M_pad; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out_f32 = h->x; d.ldo = D;
+            if (more) ln_producer(d);
+            { PROF(CBAS_PROF_DOWN, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm(more ? EPI_RESID_LN : EPI_RESID, d, st)); }
+            continue;
         }
         if (f8) { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f8(h->x, D, w.ln1_w, w.ln1_b, h8, h->sc_h, sc_ld, M, D, h->cfg.layer_norm_eps, st)); }
         else { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f16(h->x, D, w.ln1_w, w.ln1_b, h->h16, M, D, h->cfg.layer_norm_eps, st)); }
@@ -460,7 +523,7 @@ int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, in
 void use_lane(cbas_enc* h, int l) {
     const cbas_enc::Lane& L = h->lanes[l];
     h->A_patch = L.A_patch; h->x = L.x; h->h16 = L.h16; h->qkv16 = L.qkv16; h->u16 = L.u16; h->cls16 = L.cls16;
-    h->sc_h = L.sc_h; h->sc_u = L.sc_u;
+    h->sc_h = L.sc_h; h->sc_u = L.sc_u; h->x16 = L.x16; h->lnst = L.lnst;
 }
 
 int forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width, int64_t frame_stride,
@@ -501,12 +564,13 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
     if (h->sync_done) (void)hipEventDestroy(h->sync_done);
     {
         void* b1[] = {h->lanes[1].A_patch, h->lanes[1].x, h->lanes[1].h16, h->lanes[1].qkv16, h->lanes[1].u16, h->lanes[1].cls16,
-                      h->lanes[1].sc_h, h->lanes[1].sc_u};
+                      h->lanes[1].sc_h, h->lanes[1].sc_u, h->lanes[1].x16, h->lanes[1].lnst};
         for (void* b : b1) if (b) (void)hipFree(b);
     }
     for (auto& t : h->pos_tables) { if (t.cos) (void)hipFree(t.cos); if (t.sin) (void)hipFree(t.sin); if (t.fac) (void)hipFree(t.fac); if (t.pos) (void)hipFree(t.pos); }
     void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->prefix_dev,
-                    h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16, h->w8, h->w8_sc, h->sc_h, h->sc_u};
+                    h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16, h->w8, h->w8_sc, h->sc_h, h->sc_u,
+                    h->w16_fold, h->fold_vec, h->x16, h->lnst};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->compute) (void)hipStreamDestroy(h->compute);
@@ -575,6 +639,16 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     }
     CREATE_TRY(hipMalloc(&h->qkv_bias_all, (int64_t)h->L * 3 * D * sizeof(float)));
     CREATE_TRY(hipMemset(h->qkv_bias_all, 0, (int64_t)h->L * 3 * D * sizeof(float)));
+
+    // LayerNorm fold: folded copies of the q|k|v and up_proj weights (+ column sums and biases), fp16 path only
+    h->fold_ok = c.precision == 0 && D % 256 == 0 && D <= 1024 && F % 256 == 0;
+    f16* wf = nullptr;
+    float* fv = nullptr;
+    if (h->fold_ok) {
+        CREATE_TRY(hipMalloc(&h->w16_fold, (int64_t)h->L * (3 * D * D + F * D) * sizeof(f16)));
+        CREATE_TRY(hipMalloc(&h->fold_vec, (int64_t)h->L * 2 * (3 * D + F) * sizeof(float)));
+        wf = h->w16_fold; fv = h->fold_vec;
+    }
 
     hipStream_t st = h->compute;
     const float* p = h->blob;
@@ -648,6 +722,18 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
             rc |= launch_pack_fp8_weight(uw, lw.wup8, lw.sup, (int)F, (int)D, (int)F, 0, st);
             rc |= launch_pack_fp8_weight(dw, lw.wdown8, lw.sdown, (int)D, (int)F, (int)D, 0, st);
         }
+        if (h->fold_ok) {
+            lw.wqkv_f = wf; wf += 3 * D * D;
+            lw.wup_f = wf; wf += F * D;
+            lw.qkv_cs = fv; fv += 3 * D;
+            lw.qkv_bf = fv; fv += 3 * D;
+            lw.up_cs = fv; fv += F;
+            lw.up_bf = fv; fv += F;
+            rc |= launch_fold_ln_weight(qw, lw.ln1_w, lw.ln1_b, qb, lw.wqkv_f, lw.qkv_cs, lw.qkv_bf, (int)D, (int)D, st);
+            rc |= launch_fold_ln_weight(kw, lw.ln1_w, lw.ln1_b, kb, lw.wqkv_f + D * D, lw.qkv_cs + D, lw.qkv_bf + D, (int)D, (int)D, st);
+            rc |= launch_fold_ln_weight(vw, lw.ln1_w, lw.ln1_b, vb, lw.wqkv_f + 2 * D * D, lw.qkv_cs + 2 * D, lw.qkv_bf + 2 * D, (int)D, (int)D, st);
+            rc |= launch_fold_ln_weight(uw, lw.ln2_w, lw.ln2_b, lw.up_b, lw.wup_f, lw.up_cs, lw.up_bf, (int)F, (int)D, st);
+        }
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b, qb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b + D, kb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
         CREATE_TRY(hipMemcpyAsync(lw.qkv_b + 2 * D, vb, D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -680,6 +766,12 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         CREATE_TRY(hipMemsetAsync(h->sc_h, 0, sch_elems * 4, st));
         CREATE_TRY(hipMemsetAsync(h->sc_u, 0, scu_elems * 4, st));
     }
+    if (h->fold_ok) {
+        CREATE_TRY(hipMalloc(&h->x16, h->rows_cap * D * sizeof(f16)));
+        CREATE_TRY(hipMalloc(&h->lnst, 4 * h->rows_cap * sizeof(float2)));
+        CREATE_TRY(hipMemsetAsync(h->x16, 0, h->rows_cap * D * sizeof(f16), st));
+        CREATE_TRY(hipMemsetAsync(h->lnst, 0, 4 * h->rows_cap * sizeof(float2), st));
+    }
     const int64_t cls_elems = round_up(c.max_batch, 128) * (3 * D + F);
     CREATE_TRY(hipMalloc(&h->cls16, cls_elems * sizeof(f16)));
     CREATE_TRY(hipMemsetAsync(h->cls16, 0, cls_elems * sizeof(f16), st));
@@ -694,6 +786,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         h->n_lanes = (e && atoi(e) == 1) ? 1 : 2;
         cbas_enc::Lane& L0 = h->lanes[0];
         L0.A_patch = h->A_patch; L0.x = h->x; L0.h16 = h->h16; L0.qkv16 = h->qkv16; L0.u16 = h->u16; L0.cls16 = h->cls16; L0.sc_h = h->sc_h; L0.sc_u = h->sc_u; L0.stream = h->compute;
+        L0.x16 = h->x16; L0.lnst = h->lnst;
         if (h->n_lanes == 2) {
             cbas_enc::Lane& L1 = h->lanes[1];
             CREATE_TRY(hipMalloc(&L1.A_patch, h->prow_cap * 512 * sizeof(f16)));
@@ -706,6 +799,12 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
                 CREATE_TRY(hipMalloc(&L1.sc_u, scu_elems * 4));
                 CREATE_TRY(hipMemsetAsync(L1.sc_h, 0, sch_elems * 4, st));
                 CREATE_TRY(hipMemsetAsync(L1.sc_u, 0, scu_elems * 4, st));
+            }
+            if (h->fold_ok) {
+                CREATE_TRY(hipMalloc(&L1.x16, h->rows_cap * D * sizeof(f16)));
+                CREATE_TRY(hipMalloc(&L1.lnst, 4 * h->rows_cap * sizeof(float2)));
+                CREATE_TRY(hipMemsetAsync(L1.x16, 0, h->rows_cap * D * sizeof(f16), st));
+                CREATE_TRY(hipMemsetAsync(L1.lnst, 0, 4 * h->rows_cap * sizeof(float2), st));
             }
             CREATE_TRY(hipMalloc(&L1.cls16, cls_elems * sizeof(f16)));
             CREATE_TRY(hipMemsetAsync(L1.cls16, 0, cls_elems * sizeof(f16), st));
@@ -980,6 +1079,7 @@ extern "C" int cbas_enc_set_prune_last_layer(cbas_enc* h, int enable) {
 extern "C" int cbas_enc_debug_option(cbas_enc* h, const char* name, int value) {
     if (!h || !name) return cbas_fail(CBAS_EINVAL, "null argument");
     if (!strcmp(name, "rope_lds")) { h->rope_in_lds = value != 0; return CBAS_OK; }
+    if (!strcmp(name, "ln_fold")) { h->ln_fold = value != 0; return CBAS_OK; }
     return cbas_fail(CBAS_EINVAL, "unknown debug option '%s'", name);
 }
 
@@ -1058,6 +1158,8 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100;
     // tile >= 200: q|k|v epilogue (RoPE tables of 196 patches, 201 tokens per frame, D = N / 3) with tile id = tile - 200
     // + 500: MX-fp8 operands (random e4m3 bytes, unit scales; the GELU form then writes fp8 + scales): timing only
+    const bool ln = tile >= 2000;            // 2000 + ...: the LayerNorm-fold form of the epilogue (timing only: zero statistics)
+    if (ln) tile -= 2000;
     const bool want_stamps = tile >= 1000;   // 1000 + tile: also print the block timeline statistics
     tile %= 1000;
     const bool f8 = tile >= 500;
@@ -1108,7 +1210,21 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
         p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3; p.tokens_per_frame = 201; p.n_prefix = 5;
         p.rope_fac = rope; p.rope_nh = 14; p.rope_nw = 14; p.rope_magic = (unsigned)((1ull << 32) / 14u) + 1u;   // zeros: timing only
     }
-    const GemmEpilogue epi = qkv ? EPI_QKV : resid ? EPI_RESID : f8 ? EPI_GELU_F8 : EPI_GELU;
+    float2* lnst = nullptr;
+    f16* x16 = nullptr;
+    float* colsum = nullptr;
+    if (ln) {
+        if (f8) return cbas_fail(CBAS_EINVAL, "the LayerNorm fold is an fp16 form");
+        HIP_TRY(hipMalloc(&lnst, 4 * M_pad * sizeof(float2)));
+        HIP_TRY(hipMemset(lnst, 0, 4 * M_pad * sizeof(float2)));
+        HIP_TRY(hipMalloc(&colsum, (int64_t)N * 4));
+        HIP_TRY(hipMemset(colsum, 0, (int64_t)N * 4));
+        if (resid) { HIP_TRY(hipMalloc(&x16, M_pad * (int64_t)N * 2)); p.x16_out = x16; p.ln_out = lnst; }
+        else { p.ln_in = lnst; p.ln_colsum = colsum; p.ln_parts = K / 256; p.ln_eps = 1.0f; }
+        p.ln_ld = (int)M_pad;
+        if (!p.tile) p.tile = GEMM_TILE_PP_AUTO;
+    }
+    const GemmEpilogue epi = qkv ? (ln ? EPI_QKV_LN : EPI_QKV) : resid ? (ln ? EPI_RESID_LN : EPI_RESID) : f8 ? EPI_GELU_F8 : (ln ? EPI_GELU_LN : EPI_GELU);
     int rc = launch_gemm(epi, p, 0);
     if (rc) return cbas_fail(CBAS_EINVAL, "launch_gemm failed for tile %d (rc=%d)", tile, rc);
     HIP_TRY(hipDeviceSynchronize());
@@ -1157,6 +1273,7 @@ extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, f
     if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, cs, 8, hipMemcpyDeviceToHost));
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(cs); if (x32) hipFree(x32); if (rope) hipFree(rope); if (sc8) hipFree(sc8);
+    if (lnst) hipFree(lnst); if (x16) hipFree(x16); if (colsum) hipFree(colsum);
     return CBAS_OK;
 }
 

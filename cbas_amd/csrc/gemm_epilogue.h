@@ -18,6 +18,40 @@ __device__ __forceinline__ f32x4 rope_rot(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
     return __builtin_elementwise_fma(a, c, t);
 }
 
+// ---- LayerNorm fold helpers -----------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int LN_BLOCK = 256;                  // columns per statistics block = one N tile of the producer
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), every lane gets the total; fixed order, plain VALU
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);      // row_half_mirror: the other quad of the 8
+    v += dpp_f32<0x140>(v);      // row_mirror: the other half of the 16
+    return v;
+}
+// pooled statistics of nb equal blocks of n values each, from {sum_b, M2_b about the block mean}:
+//   sum = sum_b sum_b,   M2 = sum_b M2_b + n sum_b (sum_b / n - sum / (nb n))^2          (exact; Chan et al.)
+template <int NB>
+__device__ __forceinline__ f32x2 ln_pool(const f32x2 (&b)[NB], int nb, float n) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (k < nb) { s += b[k][0]; q += b[k][1]; }
+    const float mean = s / ((float)nb * n);
+    float between = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (k < nb) {
+            const float d = b[k][0] * (1.0f / n) - mean;
+            between = fmaf(d, d, between);
+        }
+    return f32x2{s, fmaf(n, between, q)};
+}
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, int head_col0, int lane,
                                                   const f32x4 (&acc)[4]) {
@@ -100,10 +134,15 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
 // `pre` is called once, after the epilogue's first global loads have been issued (they would otherwise queue behind
 // it): the persistent kernel issues the next tile's first LDS-DMAs there.
-template <int EPI, int TM, typename Pre = NoPrefetch>
+// EPI_RESID_LN: ln_red = this wave's slot in the workgroup's statistics image, f32x2 [rows of the wave][4 column waves]
+// (entry (r, wc) at ln_red[r * 4]); the caller pools the four 64-column blocks of a row after a barrier.
+// EPI_QKV_LN / EPI_GELU_LN: ln_red = (mean, rstd) of this wave's rows, f32x2 [rows of the wave], written by the caller.
+template <int EPIX, int TM, typename Pre = NoPrefetch>
 __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_base, int head_col0, int lane,
                                                    const f32x4 (&acc)[TM][4], char* scratch, Pre pre = Pre(),
-                                                   const float* rope_lds = nullptr) {
+                                                   const float* rope_lds = nullptr, f32x2* ln_red = nullptr) {
+    constexpr int EPI = epi_base(EPIX);
+    constexpr bool LN = EPIX != EPI;
     const int li = lane & 15, g = lane >> 4;
     if (EPI == EPI_PATCH) {                      // small GEMM with a row scatter: keep the direct form
         pre();
@@ -140,14 +179,45 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 *reinterpret_cast<f32x4*>(sc + li * 256 + q * 16) = acc[i][j];
             }
             asm volatile("" ::: "memory");
+            uint2 h16r[4];                                              // LN: the fp16 row segments of this slab
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int r = it * 4 + g;                              // row within the 16-row slab
                 const f32x4 y = *reinterpret_cast<const f32x4*>(sc + r * 256 + ((li ^ r) << 4));
                 const int m = row_base + i * 16 + r;
-                if (m < p.M)
-                    *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + head_col0 + li * 4) =
-                        (y + bvt) * lvt + xs[i & 1][it];
+                const f32x4 xn = (y + bvt) * lvt + xs[i & 1][it];
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + head_col0 + li * 4) = xn;
+                if (LN) {
+                    // LayerNorm fold, producer side: the statistics of this row's 64 columns - they sit in the 16 lanes of
+                    // one DPP row: block sum, then M2 about the block mean (two dependent reductions: as robust as
+                    // LayerNorm's own two passes) - and the fp16 copy of the row segment (the next GEMM's A operand)
+                    const float bs = row16_sum((xn[0] + xn[1]) + (xn[2] + xn[3]));
+                    const f32x4 d = xn - bs * (1.0f / 64.0f);
+                    const float bq = row16_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                    if (li == 0) ln_red[(i * 16 + r) * 4] = f32x2{bs, bq};
+                    const f32x4 c = __builtin_elementwise_max(__builtin_elementwise_min(xn, f32x4{65504.f, 65504.f, 65504.f, 65504.f}),
+                                                              f32x4{-65504.f, -65504.f, -65504.f, -65504.f});
+                    union { f16x4 h; uint2 u; } cv;
+                    cv.h = f16x4{(f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+                    h16r[it] = cv.u;
+                }
+            }
+            if (LN) {
+                // The epilogue is store-ISSUE bound: two 8-byte stores per row pair would cost as much as two more 16-byte
+                // ones.  Lanes li and li ^ 1 trade halves instead (one DPP quad swap): the even lane stores 8 columns of row
+                // `it`, the odd lane 8 columns of row `it + 1` - one 16-byte store per lane and row PAIR.
+                const bool odd = li & 1;
+#pragma unroll
+                for (int it = 0; it < 4; it += 2) {
+                    const uint2 send = odd ? h16r[it] : h16r[it + 1];      // what the partner's row needs from this lane
+                    uint2 recv;
+                    recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xf, 0xf, true);
+                    recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xf, 0xf, true);
+                    const uint2 own = odd ? h16r[it + 1] : h16r[it];
+                    const uint4 outv = odd ? uint4{recv.x, recv.y, own.x, own.y} : uint4{own.x, own.y, recv.x, recv.y};
+                    const int m = row_base + i * 16 + (it + (odd ? 1 : 0)) * 4 + g;
+                    if (m < p.M) *reinterpret_cast<uint4*>(p.x16_out + (size_t)m * p.N + head_col0 + (li & ~1) * 4) = outv;
+                }
             }
             if (i + 2 < TM) load_x(i + 2, xs[i & 1]);
             asm volatile("" ::: "memory");
@@ -251,6 +321,13 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
             load_rope(0);
             if (TM > 1) load_rope(1);
         }
+        // LayerNorm fold, consumer side: A was raw fp16 x and W = fp16(gamma o W).  (mean, rstd) of the tile's rows were
+        // pooled from the producer's per-N-tile partials once per tile, at its top, and sit in LDS (ln_red = this wave's rows)
+        f32x4 lnc[4];
+        if (LN) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lnc[j] = *reinterpret_cast<const f32x4*>(p.ln_colsum + head_col0 + j * 16 + g * 4);
+        }
         pre();
         // PS slabs of 16 rows per pass through the scratch (two alternating regions: the LDS is in order per wave, so a
         // pass may overwrite what the pass before last has read).  PS = 1: the stores of a slab are in flight while
@@ -264,8 +341,15 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 const int i = half * PS + ii;
                 if (i >= TM) break;                                     // compile-time after unrolling
                 f32x4 v[4];
+                if (LN) {
+                    const f32x2 st = ln_red[i * 16 + li];                  // (mean, rstd) of row row_base + i*16 + li
+                    const float mu = st[0], rs = st[1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
+                    for (int j = 0; j < 4; ++j) v[j] = __builtin_elementwise_fma(acc[i][j] - lnc[j] * mu, f32x4{rs, rs, rs, rs}, bv[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
+                }
                 if (EPI == EPI_QKV) {
                     if (rope) {
                         const int sl = i & 1;

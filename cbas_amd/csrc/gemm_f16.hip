@@ -215,6 +215,7 @@ int pick_tile(const GemmParams& p) {
 
 static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream) {
     if (tile >= GEMM_TILE_PP_256x256 && tile <= GEMM_TILE_PP_AUTO) return launch_gemm_8ph(epi, p, tile, stream);
+    if (epi_base(epi) != epi) return -3;              // the LayerNorm fold exists in the ping-pong kernel only
     if (tile == GEMM_TILE_SKINNY) return launch_gemm_skinny(epi, p, stream);
     switch (epi) {
         case EPI_PATCH: return launch_epi<EPI_PATCH>(p, tile, stream);
@@ -231,7 +232,7 @@ int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
     if (!p.group_m) p.group_m = gm_env > 0 ? gm_env : 1;
     if (!p.lda) p.lda = p.K;
     if (p.N % 128 || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
-    if (epi == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;
+    if (epi_base(epi) == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;
     if (p.A8) {           // MX-fp8 operands exist only in the ping-pong kernel; small problems take its 128-row tile
         if (p.N % 256) return -1;
         const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
@@ -241,6 +242,7 @@ int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
     if (epi == EPI_GELU_F8) return -1;
     const int tile = pick_tile(p);
     int rc = dispatch_gemm(epi, p, tile, stream);
-    if (rc == -1 && tile != GEMM_TILE_128x128) rc = dispatch_gemm(epi, p, GEMM_TILE_128x128, stream);   // shape not tileable that way
+    if (rc == -3) return -1;
+    if (rc == -1 && tile != GEMM_TILE_128x128 && epi_base(epi) == epi) rc = dispatch_gemm(epi, p, GEMM_TILE_128x128, stream);   // shape not tileable that way
     return rc;
 }

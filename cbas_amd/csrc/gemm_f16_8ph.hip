@@ -82,7 +82,7 @@ constexpr int pp_lds_kernel() {
 // K-tile is already in flight into buffer 0 (its latency - most of the prologue - hides under the epilogue).
 template <int EPI, int TA, int TB, bool F8>
 __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int first, int n_kind, int stride, int base_row,
-                                         int tiles_n, const float* rope_lds) {
+                                         int tiles_n, const float* rope_lds, char* ln_lds) {
     constexpr int TM = TA + TB;                      // 16-row MFMA tiles per wave
     constexpr int WROWS = 16 * TM;                   // rows of C per wave
     constexpr int BM = 2 * WROWS;
@@ -201,9 +201,26 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         sb_off = 1024 + (wc * 64 + frow) * 4 + fchunk;          // + (h * 2 + j) * 64
     };
 
+    // LayerNorm fold, consumer side: per-N-tile statistics of row row0 + tid (threads of the first four waves)
+    constexpr bool LNC = EPI == EPI_QKV_LN || EPI == EPI_GELU_LN;
+    f32x2 lnp[4];
+    auto load_lnp = [&] {                              // uses row0 as set_tile left it: this tile's, or the NEXT tile's
+        if constexpr (LNC) {
+            if (tid < BM) {
+                int m = row0 + tid;
+                m = m < p.M ? m : p.M - 1;
+                const f32x2* src = reinterpret_cast<const f32x2*>(p.ln_in) + m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < p.ln_parts) lnp[k] = src[(size_t)k * p.ln_ld];
+            }
+        }
+    };
+
     f32x4 acc[TM][4];
     unsigned long long t_start = 0, t_top = 0, t_pro = 0, t_loop = 0, r_pro = 0, r_loop = 0;   // r_*: s_memrealtime (100 MHz)
     if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+    load_lnp();
     stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3);      // K-tile 0 of the first tile
 
     // fragments: fp16 form = two 16-byte k-halves per 16-row tile; F8 form = the same two reads joined into the
@@ -333,6 +350,16 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         stage(1, 1, 0); stage(1, 1, 1); stage(1, 1, 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (LNC) {
+            // LayerNorm fold, consumer side: thread r of the first four waves pools the statistics of row row0 + r - one
+            // record per N tile of the producer, fetched under the previous tile's epilogue (load_lnp) - into (mean, rstd)
+            // for this tile's epilogue; every K-loop barrier lies between this write and those reads
+            if (tid < BM) {
+                const f32x2 st = ln_pool<4>(lnp, p.ln_parts, (float)LN_BLOCK);
+                const float inv_d = 1.0f / (float)(p.ln_parts * LN_BLOCK);
+                reinterpret_cast<f32x2*>(ln_lds)[tid] = f32x2{st[0] * inv_d, 1.0f / sqrtf(st[1] * inv_d + p.ln_eps)};
+            }
+        }
         if (p.stamps) { t_pro = __builtin_amdgcn_s_memtime(); r_pro = __builtin_amdgcn_s_memrealtime(); }
         if (wr == 1) __builtin_amdgcn_s_barrier();        // stagger the second wave group by one barrier
 
@@ -350,8 +377,22 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         if (has_next) set_tile(next);                     // the staging offsets now describe the NEXT tile
         // every wave is past the loop: buffer 0 is free, and the scratch below lies over buffer 1
         gemm_epilogue_tile<EPI, TM>(p, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
-            if (has_next) { stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
-        }, rope_lds);
+            if (has_next) { load_lnp(); stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
+        }, rope_lds, EPI == EPI_RESID_LN ? reinterpret_cast<f32x2*>(ln_lds) + (wr * WROWS) * 4 + wc
+                                         : reinterpret_cast<f32x2*>(ln_lds) + wr * WROWS);
+        if constexpr (EPI == EPI_RESID_LN) {
+            // LayerNorm fold, producer side: the four column waves of a row group have left the statistics of their 64
+            // columns in LDS; pool them into ONE record per row and N tile (the consumer then pools N / 256 records).
+            // This barrier is also the one that frees the epilogue scratch for the next prologue.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < BM) {
+                const f32x2* e = reinterpret_cast<const f32x2*>(ln_lds) + tid * 4;
+                const f32x2 blk[4] = {e[0], e[1], e[2], e[3]};
+                const int m = erow - wr * WROWS + tid;
+                if (m < p.M) reinterpret_cast<f32x2*>(p.ln_out)[(size_t)((ecol - wc * 64) / LN_BLOCK) * p.ln_ld + m] = ln_pool<4>(blk, 4, 64.0f);
+            }
+        }
         if (p.stamps && id == first && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
@@ -366,8 +407,10 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         id = next;
         // the next prologue refills buffer 1: every wave must be done with its scratch (raw barrier: the K-tile 0
         // LDS-DMA stays in flight across it)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (EPI != EPI_RESID_LN) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 #undef CBAS_SEG_BARRIER
 }
@@ -380,7 +423,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGr
     const int G = gridDim.x;                                   // a multiple of 8 whenever a workgroup gets > 1 tile
     // q|k|v: the factorised RoPE table lives in LDS behind the staging buffers for the life of the workgroup
     const float* rope_lds = nullptr;
-    if (EPI == EPI_QKV && p.rope_fac) {
+    // LayerNorm fold: EPI_RESID_LN f32x2 [256 rows][4 column waves]; EPI_QKV_LN / EPI_GELU_LN f32x2 [256 rows] (mean, rstd),
+    // behind the q|k|v kernel's RoPE table
+    char* const ln_lds = smem + pp_lds_kernel<TA, TB, TAIL, F8>() +
+                         (epi_base(EPI) == EPI_QKV && p.rope_fac ? (p.rope_nh + p.rope_nw) * 128 : 0);
+    if (epi_base(EPI) == EPI_QKV && p.rope_fac) {
         float* dst = reinterpret_cast<float*>(smem + pp_lds_kernel<TA, TB, TAIL, F8>());
         const int n4 = (p.rope_nh + p.rope_nw) * 8;            // 16-byte pieces
         for (int i = threadIdx.x; i < n4; i += 512)
@@ -390,13 +437,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGr
     }
     int first = blockIdx.x;
     if (first < g.main_blocks) {
-        pp_tiles<EPI, TA, TB, F8>(p, smem, first, g.main_blocks, G, 0, tiles_n, rope_lds);
+        pp_tiles<EPI, TA, TB, F8>(p, smem, first, g.main_blocks, G, 0, tiles_n, rope_lds, ln_lds);
         first += ((g.main_blocks - 1 - first) / G + 1) * G;    // this workgroup's first id past the main tiles
     }
     if (TAIL && first < g.n_tiles) {
         // the first tail tile's K-tile 0 is not prefetched across the kind switch: drain the LDS before restaging
         __syncthreads();
-        pp_tiles<EPI, 2, 2, F8>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n, rope_lds);
+        pp_tiles<EPI, 2, 2, F8>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n, rope_lds, ln_lds);
     }
 }
 
@@ -412,7 +459,8 @@ int pp_cus() {
 template <int EPI, int TA, int TB, int TAIL, bool F8>
 int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     constexpr int BM = 32 * (TA + TB);
-    constexpr int lds = pp_lds_kernel<TA, TB, TAIL, F8>() + (EPI == EPI_QKV ? ROPE_LDS_ROWS * 128 : 0);
+    constexpr int lds = pp_lds_kernel<TA, TB, TAIL, F8>() + (epi_base(EPI) == EPI_QKV ? ROPE_LDS_ROWS * 128 : 0) +
+                        (EPI == EPI_RESID_LN ? 256 * 4 * 8 : EPI == EPI_QKV_LN || EPI == EPI_GELU_LN ? 256 * 8 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -440,7 +488,8 @@ int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
     const int grid = persist && g.n_tiles > slots ? slots : g.n_tiles;
     // the launch asks only for the table rows this grid has (224^2: 3.5 KiB), not the ROPE_LDS_ROWS the attribute allows:
     // what is left of the 160 KiB decides which kernels of the other compute lane can share the CU
-    const int lds_launch = pp_lds_kernel<TA, TB, TAIL, F8>() + (EPI == EPI_QKV && p.rope_fac ? (p.rope_nh + p.rope_nw) * 128 : 0);
+    const int lds_launch = pp_lds_kernel<TA, TB, TAIL, F8>() + (epi_base(EPI) == EPI_QKV && p.rope_fac ? (p.rope_nh + p.rope_nw) * 128 : 0) +
+                           (EPI == EPI_RESID_LN ? 256 * 4 * 8 : EPI == EPI_QKV_LN || EPI == EPI_GELU_LN ? 256 * 8 : 0);
     hipLaunchKernelGGL((gemm_f16_8ph_kernel<EPI, TA, TB, TAIL, F8>), dim3(grid), dim3(512), lds_launch, stream, p, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -538,6 +587,12 @@ int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p_in, int tile, hipStrea
         case EPI_QKV:   return launch_8ph_epi<EPI_QKV, false>(p, tile, stream);
         case EPI_RESID: return launch_8ph_epi<EPI_RESID, false>(p, tile, stream);
         case EPI_GELU:  return launch_8ph_epi<EPI_GELU, false>(p, tile, stream);
+        // LayerNorm fold (fp16 only): the statistics are pooled over N tiles of 256 columns, at most four of them
+        case EPI_QKV_LN:   return p.ln_in && p.ln_colsum && p.ln_parts >= 1 && p.ln_parts <= 4 && p.K == p.ln_parts * 256
+                                  ? launch_8ph_epi<EPI_QKV_LN, false>(p, tile, stream) : -1;
+        case EPI_GELU_LN:  return p.ln_in && p.ln_colsum && p.ln_parts >= 1 && p.ln_parts <= 4 && p.K == p.ln_parts * 256
+                                  ? launch_8ph_epi<EPI_GELU_LN, false>(p, tile, stream) : -1;
+        case EPI_RESID_LN: return p.x16_out && p.ln_out ? launch_8ph_epi<EPI_RESID_LN, false>(p, tile, stream) : -1;
         default: return -1;
     }
 }

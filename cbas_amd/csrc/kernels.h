@@ -12,7 +12,12 @@ enum GemmEpilogue {
     EPI_RESID = 2,   // x[m][n] += (acc + bias[n]) * lambda[n]                        (fp32 in/out)
     EPI_GELU  = 3,   // u[m][n] = gelu_erf(acc + bias[n])                             (fp16 out)
     EPI_GELU_F8 = 4, // the same, stored as MX-fp8: e4m3 bytes + one E8M0 scale per 32 columns (precision 2)
+    // LayerNorm folded into the GEMMs around it (gemm_f16_8ph.hip only; GemmParams "LayerNorm fold" fields):
+    EPI_QKV_LN = 5,   // EPI_QKV on raw fp16 x with W = fp16(gamma o W): rstd * (acc - mean * colsum) + bias', then as EPI_QKV
+    EPI_GELU_LN = 6,  // EPI_GELU likewise
+    EPI_RESID_LN = 7, // EPI_RESID that also writes fp16 x and the per-row statistics the next EPI_*_LN needs
 };
+constexpr int epi_base(int epi) { return epi == EPI_QKV_LN ? EPI_QKV : epi == EPI_GELU_LN ? EPI_GELU : epi == EPI_RESID_LN ? EPI_RESID : epi; }
 
 enum GemmTile { GEMM_TILE_AUTO = 0, GEMM_TILE_128x128 = 1, GEMM_TILE_256x128 = 2, GEMM_TILE_128x256 = 3,
                 GEMM_TILE_256x256 = 4,
@@ -69,9 +74,24 @@ struct GemmParams {
     unsigned rope_magic;     // floor(2^32 / rope_nw) + 1: patch row = umulhi(patch, rope_magic)
     int D;                   // hidden size (q | k | v sections of width D)
     int sec0;                // section of output column 0 (0: the full q|k|v GEMM; 1: W holds only k|v)
+    // ---- LayerNorm folded into the GEMMs around it (gemm_f16_8ph.hip only; see "LayerNorm fold" in api_enc.hip) ----
+    // producer side, EPI_RESID_LN: besides the fp32 residual stream the epilogue writes its fp16 copy (the NEXT GEMM's A
+    // operand, un-normalised) and, per row and 256-column block (= one N tile), the statistics LayerNorm needs of it:
+    //   ln_out[(col / 256) * ln_ld + m] = { sum of the block's 256 values, sum of squares about the BLOCK mean }
+    f16* x16_out;            // [M][N]
+    float2* ln_out;          // [N / 256][ln_ld]
+    // consumer side, EPI_QKV_LN / EPI_GELU_LN: A holds raw fp16 x, W = fp16(gamma o W), bias = beta W^T + b; the epilogue
+    // forms rstd * (acc - mean * ln_colsum[n]) + bias[n] with mean / rstd pooled from the row's ln_parts blocks
+    // (exact pooled-variance formula: as robust as the two-pass form of layernorm_f16_kernel)
+    const float2* ln_in;     // [ln_parts][ln_ld]
+    const float* ln_colsum;  // [N]: sum over k of the fp16 folded weights
+    int ln_parts;            // K / 256 (<= 4)
+    int ln_ld;               // row stride of ln_in / ln_out (>= M)
+    float ln_eps;
 };
 
 int launch_gemm(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);
+
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p, int tile, hipStream_t stream);
 int launch_gemm_skinny(GemmEpilogue epi, const GemmParams& p, hipStream_t stream);     // M <= 64 (gemm_f16_skinny.hip)
 
@@ -94,6 +114,13 @@ int launch_layernorm_f16(const float* x, int64_t ldx, const float* gamma, const 
 // the same with an MX-fp8 result: out8 [M][D] e4m3 bytes, out_sc [D/128][sc_ld] block scales (GemmParams::A_sc layout)
 int launch_layernorm_f8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* out8,
                         uint32_t* out_sc, int sc_ld, int M, int D, float eps, hipStream_t stream);
+// LayerNorm fold, first layer: fp32 x [M][D] -> fp16 copy x16 [M][D] + per 64-column block statistics
+// ln_out[(col / 256) * ln_ld + m] = {sum, sum of squares about the block mean} (what EPI_RESID_LN writes for later layers)
+int launch_ln_stats_x16(const float* x, f16* x16, float2* ln_out, int ln_ld, int M, int D, hipStream_t stream);
+// LayerNorm fold, create time: W [N][K] fp32, gamma / beta [K], b [N] ->
+//   Wf [N][K] = fp16(gamma_k W_nk),  colsum[n] = sum_k float(Wf_nk),  biasf[n] = b[n] + sum_k beta_k W_nk
+int launch_fold_ln_weight(const float* W, const float* gamma, const float* beta, const float* b, f16* Wf, float* colsum,
+                          float* biasf, int N, int K, hipStream_t stream);
 // Final LayerNorm on the CLS row of every frame: x[b*T] -> cls_f32[b][D] / cls_f16[b][D]
 int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
                           f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream);

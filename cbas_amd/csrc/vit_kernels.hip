@@ -174,6 +174,57 @@ __global__ __launch_bounds__(256) void layernorm_f8_kernel(const float* __restri
     }
 }
 
+// LayerNorm fold, first layer: what EPI_RESID_LN leaves behind for the later ones.  One wave per row; vector k of a lane
+// (columns 4 (lane + 64 k) .. +3) lies in 256-column block k, so a block's statistics are one wave reduction each:
+// the sum, then the sum of squares about the block mean.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_stats_x16_kernel(const float* __restrict__ x, f16* __restrict__ x16,
+                                                           float2* __restrict__ ln_out, int ln_ld, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const f32x4 v = xr[lane + 64 * k];
+        const float bs = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+        const f32x4 d = v - bs * (1.0f / 256.0f);
+        const float bq = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+        const f32x4 c = __builtin_elementwise_max(__builtin_elementwise_min(v, f32x4{65504.f, 65504.f, 65504.f, 65504.f}),
+                                                  f32x4{-65504.f, -65504.f, -65504.f, -65504.f});
+        const f16x4 h = {(f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+        reinterpret_cast<f16x4*>(x16 + (size_t)row * D)[lane + 64 * k] = h;
+        if (lane == 0) ln_out[(size_t)k * ln_ld + row] = float2{bs, bq};
+    }
+}
+
+// LayerNorm fold, create time.  One 256-thread block per output row n:
+//   Wf[n][k] = fp16(gamma[k] W[n][k]);  colsum[n] = sum_k float(Wf[n][k]);  biasf[n] = b[n] + sum_k beta[k] W[n][k]
+// colsum is taken over the ROUNDED weights: rstd (acc - mean colsum) then cancels the mean exactly as the MFMA saw it.
+__global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ b,
+                                                             f16* __restrict__ Wf, float* __restrict__ colsum,
+                                                             float* __restrict__ biasf, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float cs = 0.f, bs = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const f16 wf = (f16)(gamma[k] * w);
+        Wf[(size_t)n * K + k] = wf;
+        cs += (float)wf;
+        bs = fmaf(beta[k], w, bs);
+    }
+    cs = wave_sum(cs);
+    bs = wave_sum(bs);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = cs; red[1][tid >> 6] = bs; }
+    __syncthreads();
+    if (tid == 0) {
+        colsum[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        biasf[n] = b[n] + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void final_norm_cls_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ cls_f32,
@@ -823,6 +874,24 @@ int launch_layernorm_f16(const float* x, int64_t ldx, const float* gamma, const 
         case 4: hipLaunchKernelGGL(layernorm_f16_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
         default: return -1;
     }
+    return CHECK_LAUNCH();
+}
+
+int launch_ln_stats_x16(const float* x, f16* x16, float2* ln_out, int ln_ld, int M, int D, hipStream_t stream) {
+    if (D % 256 || D > 1024) return -1;
+    const dim3 grid((M + 3) / 4), block(256);
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(ln_stats_x16_kernel<1>, grid, block, 0, stream, x, x16, ln_out, ln_ld, M, D); break;
+        case 2: hipLaunchKernelGGL(ln_stats_x16_kernel<2>, grid, block, 0, stream, x, x16, ln_out, ln_ld, M, D); break;
+        case 3: hipLaunchKernelGGL(ln_stats_x16_kernel<3>, grid, block, 0, stream, x, x16, ln_out, ln_ld, M, D); break;
+        default: hipLaunchKernelGGL(ln_stats_x16_kernel<4>, grid, block, 0, stream, x, x16, ln_out, ln_ld, M, D); break;
+    }
+    return CHECK_LAUNCH();
+}
+
+int launch_fold_ln_weight(const float* W, const float* gamma, const float* beta, const float* b, f16* Wf, float* colsum,
+                          float* biasf, int N, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_ln_weight_kernel, dim3(N), dim3(256), 0, stream, W, gamma, beta, b, Wf, colsum, biasf, K);
     return CHECK_LAUNCH();
 }
 

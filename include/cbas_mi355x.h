@@ -165,10 +165,15 @@ int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int
                               int stop_layer, int stop_stage);
 int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes);
 
-/* Bring-up / tests: switch an implementation detail of the handle (never a result: every option's two settings are
- * bit-identical, which is what the tests that use this prove).  Options:
+/* Bring-up / tests: switch an implementation detail of the handle.  Options:
  *   "rope_lds"  1 (default): the q|k|v epilogue reads the RoPE angles, factorised by axis, from LDS; 0: from the [P][64]
- *               table in global memory ([tf]:96-121, 168-200 either way). */
+ *               table in global memory ([tf]:96-121, 168-200 either way).  Bit-identical results.
+ *   "ln_fold"   1: LayerNorm ([tf]:404, 410) is folded into the GEMMs around it - o_proj / down_proj write a fp16 copy of
+ *               the residual stream and per-row statistics, q|k|v / up_proj run on it with gamma folded into their weights and
+ *               apply mean / rstd in their epilogues; 0: separate LayerNorm kernels.  The two settings agree to fp16 rounding
+ *               (both within the 1e-3 CLS bar, both batch-invariant); fp16 path with hidden_size a multiple of 256 only.
+ *               Default 0: with two batches in flight the separate kernels already hide under the other lane's GEMMs
+ *               (measured +0 ... +1 % for the fold; -5 % of kernel time with a single batch in flight). */
 int cbas_enc_debug_option(cbas_enc* h, const char* name, int value);
 
 /* Bring-up: time the fp16 GEMM kernel alone on random operands (GELU epilogue, M x N x K,

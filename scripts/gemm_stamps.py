@@ -11,6 +11,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 12864
 shapes = os.environ.get("CBAS_STAMP_SHAPES", "up,qkv,oproj,down").split(",")
 f8 = 500 if os.environ.get("CBAS_STAMP_F8") == "1" else 0           # the MX-fp8 kernels instead
+f8 += 2000 if os.environ.get("CBAS_STAMP_LN") == "1" else 0          # the LayerNorm-fold forms of the epilogues
 for name, m, n, k, eoff in [("up (gelu)", M, 3072, 768, 0), ("qkv (rope)", M, 2304, 768, 200), ("oproj", M, 768, 768, 100), ("down", M, 768, 3072, 100)]:
     if name.split()[0] not in shapes:
         continue

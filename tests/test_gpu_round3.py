@@ -241,3 +241,106 @@ def test_encode_file_on_a_compressed_video_equals_its_decoded_frames(tmp_path):
 def _closing(obj):
     import contextlib
     return contextlib.closing(obj)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LayerNorm folded into the GEMMs around it (cbas_enc_debug_option "ln_fold"; csrc/gemm_epilogue.h, api_enc.hip run_blocks).
+# Off by default (a measured wash with two batches in flight); when switched on it must meet the same bars.
+# ------------------------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)
+
+
+@pytest.mark.parametrize("name,cfgname,hw,batch", [("vitb16_224_noise", "vitb16", 224, 64), ("vitb16_256", "vitb16", 256, 8),
+                                                   ("vitl16_224", "vitl16", 224, 8), ("vitl16_518", "vitl16", 518, 4)])
+def test_ln_fold_meets_the_cls_bar_and_is_batch_invariant(golden_dir, name, cfgname, hw, batch):
+    from cbas_amd.encoder import DinoEncoder
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = C.NAMED_VIT[cfgname]
+    n = min(int(g["n"]), batch)
+    mk = synth.noise_frames if str(g["kind"]) == "noise" else synth.cage_frames
+    gold = mk(int(g["frame_seed"]), int(g["n"]), hw, hw)[:n]
+    fill = synth.noise_frames(77, batch - n, hw, hw) if batch > n else gold[:0]
+    fr = torch.from_numpy(np.concatenate([gold, fill])).cuda()
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=batch, max_frame=(hw, hw))
+    try:
+        _, off32 = enc.encode_u8(fr)
+        enc.debug_option("ln_fold", 1)
+        on16, on32 = enc.encode_u8(fr)
+        _, small32 = enc.encode_u8(fr[:n])                      # the golden frames alone: other tiles, other tile counts
+        perm = torch.from_numpy(np.random.default_rng(1).permutation(batch)).cuda()
+        _, perm32 = enc.encode_u8(fr[perm].contiguous())
+        torch.cuda.synchronize()
+        r_on, r_off = _rel(on32[:n].cpu().numpy(), g["cls"][:n]), _rel(off32[:n].cpu().numpy(), g["cls"][:n])
+        d = _rel(on32.cpu().numpy(), off32.cpu().numpy())
+        print(f"ln_fold {name} batch {batch}: CLS rel err vs reference golden {r_on.max():.3e} (separate LayerNorm kernels: "
+              f"{r_off.max():.3e}); folded vs separate {d.max():.3e}")
+        assert r_on.max() < 1e-3 and r_off.max() < 1e-3
+        assert d.max() < 1.5e-3
+        assert torch.equal(on32[:n], small32) and torch.equal(on32[perm], perm32)          # bit-exact batch invariance
+        assert np.array_equal(on16.cpu().numpy(), on32.cpu().numpy().astype(np.float16))
+        enc.debug_option("ln_fold", 0)
+        _, again = enc.encode_u8(fr)
+        torch.cuda.synchronize()
+        assert torch.equal(again, off32)
+    finally:
+        enc.close()
+
+
+def test_ln_fold_with_massive_activations_and_large_row_means():
+    """What real checkpoints do and random weights do not: a few residual-stream channels hundreds of times larger than the rest,
+    and rows whose MEAN is far from zero (the case where a one-pass variance would cancel catastrophically: the fold pools
+    block sums of squares about block means instead).  4-layer ViT-B against the fp32 oracle, both settings."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.ViTConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=4, num_attention_heads=12, image_size=224)
+    w = {k: v.copy() for k, v in W.synth_encoder_weights(cfg, 1234).items()}
+    hot = [7, 100, 300, 640]
+    w["model.layer.0.mlp.down_proj.bias"][hot] += 80.0 / np.abs(w["model.layer.0.layer_scale2.lambda1"][hot])
+    w["model.layer.1.mlp.down_proj.bias"] += 25.0 / np.abs(w["model.layer.1.layer_scale2.lambda1"])      # every channel: row mean >> row std
+    for nme in ("norm1", "norm2"):
+        w[f"model.layer.1.{nme}.weight"][hot] *= 5.0
+    w["embeddings.register_tokens"] = w["embeddings.register_tokens"] * 20.0
+    fr = synth.cage_frames(5, 3, 224, 224)
+    ref = PO.encode_frames(fr, w, cfg, batch=3)
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=4, max_frame=(224, 224))
+    try:
+        for fold in (0, 1):
+            enc.debug_option("ln_fold", fold)
+            _, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+            torch.cuda.synchronize()
+            r = _rel(c32.cpu().numpy(), ref)
+            print(f"massive activations + large row means, ln_fold={fold}: CLS rel err {r.max():.3e}")
+            assert np.isfinite(c32.cpu().numpy()).all() and r.max() < 1e-3, (fold, r)
+    finally:
+        enc.close()
+
+
+def test_ln_fold_dinov2_and_unsupported_widths(golden_dir):
+    """DINOv2-with-registers (key bias, LayerNorm eps 1e-6, learned position table) through the fold; a ViT-S (D = 384: no
+    whole 256-column statistics block) silently keeps the LayerNorm kernels."""
+    from cbas_amd.encoder import DinoEncoder
+    g = np.load(os.path.join(golden_dir, "dinov2reg_b14.npz"))
+    cfg = C.DINOV2_REG_B14
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(224, 224))
+    try:
+        enc.debug_option("ln_fold", 1)
+        _, c32 = enc.encode_u8(torch.from_numpy(synth.cage_frames(31, 4, 224, 224)).cuda())
+        torch.cuda.synchronize()
+        assert _rel(c32.cpu().numpy(), g["cls224"]).max() < 1e-3
+    finally:
+        enc.close()
+    cfg = C.NAMED_VIT["vits16"]
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=2, max_frame=(64, 64))
+    try:
+        fr = torch.from_numpy(synth.noise_frames(1, 2, 64, 64)).cuda()
+        _, a = enc.encode_u8(fr)
+        enc.debug_option("ln_fold", 1)
+        _, b = enc.encode_u8(fr)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        with pytest.raises(RuntimeError, match="unknown debug option"):
+            enc.debug_option("no_such_option", 1)
+    finally:
+        enc.close()
