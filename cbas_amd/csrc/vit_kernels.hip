@@ -618,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const f16* __r
 // softmax rescales and double the independent MFMA chains in flight (the kernel is dependency-bound: PMC in DESIGN.md).
 // Rows past T re-read row T-1 (finite; their scores are masked to -inf before the max).
 // ---------------------------------------------------------------------------------------------
-template <int KT>
+template <int KT, bool RS>
 __global__ __launch_bounds__(512, KT <= 4 ? 6 : 2) void attention_stream2_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls,
                                                                    void* __restrict__ out_v, uint32_t* __restrict__ out_sc, int sc_ld,
                                                                    int T, int D, int n_heads) {
@@ -662,7 +662,14 @@ __global__ __launch_bounds__(512, KT <= 4 ? 6 : 2) void attention_stream2_kernel
     };
     stage(0);
 
+    // The row sum l rides on a fifth P.V MFMA per key group against an all-ones "V" tile: every row of that product is
+    // sum_k P[k][query], so lane (g, li) holds the running sum of ITS query four times over - no adds per score, no
+    // cross-lane reduction at the end, and the sum is taken over the same fp16-rounded probabilities that multiply V.
+    // (This kernel is VALU-bound: 9 -> 4 VALU instructions per score in r2, the add was one of the four.)
+    // RS = false: the sum is kept in fp32 on the VALU (r2 form).  Measured at ViT-L/518 batch 32, same device: see DESIGN.md.
     float m = -INFINITY, l = 0.f;
+    f32x4 ol = {0.f, 0.f, 0.f, 0.f};
+    const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -711,10 +718,11 @@ __global__ __launch_bounds__(512, KT <= 4 ? 6 : 2) void attention_stream2_kernel
                     e0[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp][r], 1.4426950408889634f, -m2));
                     e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1][r], 1.4426950408889634f, -m2));
                 }
-                bs += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
+                if (!RS) bs += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
                 pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
             }
-            l = l * alpha + bs;
+            if (RS) ol = ol * alpha;
+            else l = l * alpha + bs;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
 #pragma unroll
@@ -731,11 +739,16 @@ __global__ __launch_bounds__(512, KT <= 4 ? 6 : 2) void attention_stream2_kernel
                     u.s.a = lo; u.s.b = hi;
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[s2], o[dt], 0, 0, 0);
                 }
+                if (RS) ol = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s2], ol, 0, 0, 0);
             }
         }
     }
-    l = xor16_add(l);
-    l = xor32_add(l);
+    if (RS) {
+        l = ol[0];
+    } else {
+        l = xor16_add(l);
+        l = xor32_add(l);
+    }
     if (out_sc) {
         if (wave_active) attn_store_f8(o, 1.0f / l, reinterpret_cast<uint8_t*>(out_v), out_sc, sc_ld, (size_t)b * T + q, q < nq, D, hd, g);
     } else if (q < nq) {
@@ -945,12 +958,17 @@ int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_
     // CBAS_ATTN_STREAM=2: 128-key blocks (two workgroups per CU, 235 us); 1: the first form
     static const int stream_env = [] { const char* e = getenv("CBAS_ATTN_STREAM"); return e ? atoi(e) : 3; }();
     if (stream_env == 2) {
-        hipLaunchKernelGGL(attention_stream2_kernel<8>, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
+        hipLaunchKernelGGL((attention_stream2_kernel<8, false>), dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
+                           n_heads);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (stream_env == 4) {                      // experiment: row sum on a fifth P.V MFMA against an all-ones tile
+        hipLaunchKernelGGL((attention_stream2_kernel<4, true>), dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
                            n_heads);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (stream_env == 3) {
-        hipLaunchKernelGGL(attention_stream2_kernel<4>, dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
+        hipLaunchKernelGGL((attention_stream2_kernel<4, false>), dim3(n * n_heads, nqb), dim3(512), 0, stream, qkv, q_cls, out, out_sc, sc_ld, T, D,
                            n_heads);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
