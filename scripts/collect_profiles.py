@@ -32,12 +32,14 @@ py = [sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic.py")]
 subprocess.check_call(py + [one(G + "/pmc_fetch/*/*counter_collection.csv"), one(G + "/pmc_write/*/*counter_collection.csv"),
                             os.path.join(P, "pmc_traffic.json"), one(G + "/pmc_mfma/*/*counter_collection.csv")])
 subprocess.check_call(py + [one(G + "/pmc_fetch_fp8/*/*counter_collection.csv"), one(G + "/pmc_write_fp8/*/*counter_collection.csv"),
-                            os.path.join(P, f"{dst}_pmc_traffic_fp8.json"), one(G + "/pmc_mfma_fp8/*/*counter_collection.csv")])
+                            os.path.join(P, f"{dst}_pmc_traffic_fp8.json"), one(G + "/pmc_mfma_fp8/*/*counter_collection.csv"),
+                            "ViT-B/16 precision 2 (MX-fp8), 64 frames 224x224 per launch set (scripts/quick_perf.py vitb16 64 3 224 2)"])
 if os.path.isdir(G4):
     cp(os.path.join(G4, f"{src4}_bench.json"), f"{dst}_cfg4_bench.json")
     cp(one(G4 + "/stats_lanes1/*/*kernel_stats.csv"), f"{dst}_cfg4_vitl16_518_b32_lanes1_kernel_stats.csv")
     subprocess.check_call(py + [one(G4 + "/pmc_fetch/*/*counter_collection.csv"), one(G4 + "/pmc_write/*/*counter_collection.csv"),
-                                os.path.join(P, f"{dst}_cfg4_pmc_traffic.json"), one(G4 + "/pmc_mfma/*/*counter_collection.csv")])
+                                os.path.join(P, f"{dst}_cfg4_pmc_traffic.json"), one(G4 + "/pmc_mfma/*/*counter_collection.csv"),
+                                "ViT-L/16, 32 frames 518x518 per launch set (scripts/quick_perf.py vitl16 32 2 518)"])
 
 
 def table(path, M, D, F, label):
