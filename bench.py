@@ -196,7 +196,7 @@ def main() -> None:
     ap.add_argument("--no-gates", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (compute lanes of the encoder)")
     ap.add_argument("--files", type=int, default=2, help="clips per rank of the files_path pass (0: skip it)")
-    ap.add_argument("--clip-frames", type=int, default=2048, help="frames per clip of the files_path pass")
+    ap.add_argument("--clip-frames", type=int, default=4096, help="frames per clip of the files_path pass")
     ap.add_argument("--files-dir", default=None, help="where the synthetic clips go (default: a temp dir under /dev/shm)")
     args = ap.parse_args()
 

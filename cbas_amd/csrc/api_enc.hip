@@ -1021,6 +1021,8 @@ extern "C" int cbas_enc_submit_u8_host_dev(cbas_enc* h, int slot, const uint8_t*
                                cls_f32_dev, (f16*)cls_f16_dev, true);
 }
 
+extern "C" void* cbas_enc_copy_stream(cbas_enc* h) { return h ? (void*)h->copy : nullptr; }
+
 extern "C" int cbas_enc_get_config(const cbas_enc* h, cbas_enc_config* out) {
     if (!h || !out) return cbas_fail(CBAS_EINVAL, "null argument");
     *out = h->cfg;

@@ -21,7 +21,12 @@ struct cbas_fused {
     float temperature;
     uint16_t* cls16 = nullptr;      // [capacity][D] IEEE half, device
     float* probs = nullptr;         // [capacity][C], device
-    hipStream_t st = nullptr;       // the head runs here; encoder batches are chained to it by events
+    hipStream_t st = nullptr;       // the head runs here; encoder batches are chained to it by events.  It is the ENCODER'S COPY
+                                    // STREAM, not a stream of the session's own: the head's waits already order the host->HBM
+                                    // copies (a copy into a slot waits for what was queued here), and one active stream fewer
+                                    // keeps the process at three busy hardware queues - lanes 0 / 1 and this one - which is
+                                    // worth 6 % on the pinned-host path (cbas_enc_copy_stream)
+    bool own_stream = false;
     int64_t encoded = 0, classified = 0, landed = 0;
     struct Busy { int64_t n = 0; uint64_t seq = 0; } busy[CBAS_ENC_SLOTS];
     int next_slot = 0;
@@ -115,7 +120,10 @@ extern "C" int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacit
     hipError_t e = hipGetDevice(&f->device);
     if (e == hipSuccess) e = hipMalloc(&f->cls16, (size_t)capacity_frames * f->D * sizeof(uint16_t));
     if (e == hipSuccess && f->C > 0) e = hipMalloc(&f->probs, (size_t)capacity_frames * f->C * sizeof(float));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        f->st = (hipStream_t)cbas_enc_copy_stream(enc);
+        if (!f->st) { e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking); f->own_stream = true; }
+    }
     if (e != hipSuccess) {
         cbas_fail(e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP, "cbas_fused_create: %s", hipGetErrorString(e));
         cbas_fused_destroy(f);
@@ -129,7 +137,7 @@ extern "C" void cbas_fused_destroy(cbas_fused* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)drain(f);
-    if (f->st) { (void)hipStreamSynchronize(f->st); (void)hipStreamDestroy(f->st); }
+    if (f->st) { (void)hipStreamSynchronize(f->st); if (f->own_stream) (void)hipStreamDestroy(f->st); }
     if (f->cls16) (void)hipFree(f->cls16);
     if (f->probs) (void)hipFree(f->probs);
     delete f;

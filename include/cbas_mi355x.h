@@ -145,6 +145,11 @@ int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream);
 int cbas_enc_submit_u8_host_dev(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height, int width,
                                 int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
                                 float* cls_f32_dev, uint16_t* cls_f16_dev, void* after_stream);
+/* The handle's copy stream (a hipStream_t), for work that should be ordered with its host->HBM copies rather than get a stream
+ * of its own.  The fused session runs the head there: a HIP process has FOUR hardware queues by default (GPU_MAX_HW_QUEUES)
+ * and its streams share them round-robin; with the two compute lanes, the copy stream AND a head stream all active, the
+ * pinned-host path measured 6 % slower than with three active queues (DESIGN.md, section 6 "hardware queues"). */
+void* cbas_enc_copy_stream(cbas_enc* h);
 /* The configuration the handle was created with. */
 int cbas_enc_get_config(const cbas_enc* h, cbas_enc_config* out);
 /* Use 1 or 2 compute lanes for the asynchronous forms (2 by default; 1 serialises the batches, e.g. to time
