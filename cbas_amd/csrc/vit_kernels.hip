@@ -476,159 +476,6 @@ void attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ q_cls
 }
 
 // ---------------------------------------------------------------------------------------------
-// Experiment (r3): the resident kernel with TWO query tiles interleaved per wave - two independent
-// S / softmax / P.V chains that share every K and V fragment read (each ds_read feeds two MFMAs).  Costs ~2x the
-// accumulator registers (-> 2 waves per SIMD, one 7-wave workgroup per CU instead of two).  CBAS_ATTN_PAIR=1 selects it;
-// full-frame fp16 mode with the exact-tile-count instantiations only.  Measured: see DESIGN.md section 4 (r3 item 3).
-// ---------------------------------------------------------------------------------------------
-template <int NKT, int NV>
-__global__ __launch_bounds__(512, 4)
-void attention_pair_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int D, int n_heads) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NQK = NV;
-    constexpr int NG = (NV + 1) / 2;
-    constexpr int ROWS = NQK * 16;
-    char* Vs = smem;
-    char* Ks = smem + ROWS * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int pair = blockIdx.x;
-    const int b = pair / n_heads, hd = pair - b * n_heads;
-    const size_t ld = (size_t)3 * D;
-    const f16* qbase = qkv + (size_t)b * T * ld + hd * 64;
-    const f16* kbase = qbase + D;
-    const f16* vbase = qbase + 2 * D;
-    const int g = lane >> 4, li = lane & 15;
-    const int nqt = (T + 15) >> 4;
-    auto load_q = [&](int qt, f16x8 (&qf)[2]) {
-        const int q = qt * 16 + li;
-        const int qrow = q < T ? q : T - 1;
-        qf[0] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + g * 8);
-        qf[1] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qrow * ld + 32 + g * 8);
-    };
-    // tiles of this wave: qt0 = 2 * wave, qt1 = 2 * wave + 1 (the second may not exist: it then repeats the first, unstored)
-    const int qt0 = 2 * wave, qt1 = 2 * wave + 1 < nqt ? 2 * wave + 1 : 2 * wave;
-    const bool has1 = 2 * wave + 1 < nqt, has0 = qt0 < nqt;
-    f16x8 qf[2][2] = {};
-    if (has0) { load_q(qt0, qf[0]); load_q(qt1, qf[1]); }
-    {
-        const int pr = lane >> 3, pos = lane & 7;
-        for (int p = wave; p < ROWS / 8; p += nwaves) {
-            const int r = p * 8 + pr;
-            const int rs = r < T ? r : T - 1;
-            const int kc = pos ^ ((r >> 1) & 7);
-            const int vc = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(kbase + (size_t)rs * ld + kc * 8), LDS_PTR(Ks + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(vbase + (size_t)rs * ld + vc * 8), LDS_PTR(Vs + p * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    if (!has0) return;
-    const char* kb0 = Ks + k_off(li, g);
-    const char* kb1 = Ks + k_off(li, 4 + g);
-    const char* vb[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vb[dt] = Vs + v_off(4 * g + (li >> 2), 16 * dt + 4 * (li & 3));
-    float tail_bias[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tail_bias[r] = ((NV - 1) * 16 + 4 * g + r >= T) ? -INFINITY : 0.f;
-
-    f32x4 s[2][NQK];
-#pragma unroll
-    for (int kt = 0; kt < NQK; ++kt) {
-        const f16x8 ka = *reinterpret_cast<const f16x8*>(kb0 + kt * 2048), kbq = *reinterpret_cast<const f16x8*>(kb1 + kt * 2048);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (kt == NV - 1) acc = f32x4{tail_bias[0], tail_bias[1], tail_bias[2], tail_bias[3]};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[u][0], acc, 0, 0, 0);
-            s[u][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kbq, qf[u][1], acc, 0, 0, 0);
-        }
-        if (kt & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    float sum[2];
-    f16x8 pf[2][NG];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NQK; ++kt) {
-            mx = max3_raw(mx, s[u][kt][0], s[u][kt][1]);
-            mx = max3_raw(mx, s[u][kt][2], s[u][kt][3]);
-        }
-        mx = xor16_max(mx);
-        mx = xor32_max(mx);
-        const float m2 = mx * 1.4426950408889634f;
-        float sm = 0.f;
-#pragma unroll
-        for (int grp = 0; grp < NG; ++grp) {
-            f32x4 e0, e1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e0[r] = __builtin_amdgcn_exp2f(fmaf(s[u][2 * grp][r], 1.4426950408889634f, -m2));
-                if (2 * grp + 1 < NQK) e1[r] = __builtin_amdgcn_exp2f(fmaf(s[u][2 * grp + 1 < NQK ? 2 * grp + 1 : 0][r], 1.4426950408889634f, -m2));
-            }
-            sm += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
-            pf[u][grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
-        }
-        sm = xor16_add(sm);
-        sum[u] = xor32_add(sm);
-    }
-    f32x4 o[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < NG; ++s2) {
-        f16x8 vf[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb[dt] + s2 * 4096));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb[dt] + s2 * 4096 + 2048));
-            union { struct { s16x4 a, b; } s; f16x8 v; } uu;
-            uu.s.a = lo; uu.s.b = hi;
-            vf[dt] = uu.v;
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt], pf[0][s2], o[0][dt], 0, 0, 0);
-            o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt], pf[1][s2], o[1][dt], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int q = (u ? qt1 : qt0) * 16 + li;
-        if (q < T && (u == 0 || has1)) {
-            const float inv = 1.0f / sum[u];
-            f16* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f32x4 w = o[u][dt] * inv;
-                f16x4 hv = {(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
-                *reinterpret_cast<f16x4*>(orow + 16 * dt) = hv;
-            }
-        }
-    }
-}
-
-template <int NV>
-int launch_attention_pair(const f16* qkv, f16* out, int n, int T, int D, int n_heads, hipStream_t stream) {
-    constexpr int lds = NV * 16 * 128 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pair_kernel<NV + 1, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return -2;
-        attr_set = true;
-    }
-    const int nwaves = ((T + 15) / 16 + 1) / 2;                  // one pair of tiles per wave: 7 waves at T = 201, 9 -> 8+... at 261
-    if (nwaves > 8) return -1;
-    hipLaunchKernelGGL((attention_pair_kernel<NV + 1, NV>), dim3(n * n_heads), dim3(64 * nwaves), lds, stream, qkv, out, T, D, n_heads);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Streaming variant for long token sequences (T > 288, e.g. ViT-L/16 at 518x518: T = 1029), where
 // K and V of one head (2 x 132 KB) no longer fit the LDS: one workgroup = 8 waves = 128 queries of
 // one (frame, head); keys stream through a double-buffered 64-key LDS block with an online softmax
@@ -1097,8 +944,6 @@ int launch_attention(const f16* qkv, const f16* q_cls, void* out, uint32_t* out_
     // 256x256 /16 and 224x224 /14 -> T = 261 (17 tiles); everything else takes the run-time-masked form
     static const int split_env = [] { const char* e = getenv("CBAS_ATTN_SPLIT"); return e ? atoi(e) : 1; }();    // experiments
     const bool split = split_env == 2 && !q_cls;
-    static const int pair_env = [] { const char* e = getenv("CBAS_ATTN_PAIR"); return e ? atoi(e) : 0; }();        // experiment
-    if (pair_env == 1 && nkt == 13 && !q_cls && !out_sc) return launch_attention_pair<13>(qkv, (f16*)out, n, T, D, n_heads, stream);
     if (nkt == 13) return split ? launch_attention_t<14, 13, 2>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream)
                                 : launch_attention_t<14, 13, 1>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream);
     if (nkt == 17) return split ? launch_attention_t<18, 17, 2>(qkv, q_cls, out, out_sc, sc_ld, n, T, D, n_heads, stream)
