@@ -556,10 +556,19 @@ def _stream_chunks(encoder: DinoEncoder, reader, video_len: int, progress_callba
     free = list(range(nslots))
     left: dict = {}                  # id(chunk frames) -> [frames, sub-batches not yet waited for]
 
+    landed: List[np.ndarray] = []    # rows waiting for the next flush point: the writer gets one append per chunk, as the
+                                     # reference's loop does (cbas.py:437-440), not one per 64-frame sub-batch
+
+    def hand_over():
+        if landed:
+            w.append(landed[0] if len(landed) == 1 else np.concatenate(landed))
+            landed.clear()
+        w.flush()
+
     def drain_one():
         slot, fr = inflight.popleft()
         rows, _ = encoder.wait(slot)                 # host wait: this sub-batch's H2D copy is long done
-        w.append(rows)
+        landed.append(rows)
         free.append(slot)
         ent = left[id(fr)]
         ent[1] -= 1
@@ -587,10 +596,10 @@ def _stream_chunks(encoder: DinoEncoder, reader, video_len: int, progress_callba
             if end_index % CHUNK_SIZE == 0 or end_index == video_len:
                 while len(inflight) > nslots - 1:
                     drain_one()
-                w.flush()
+                hand_over()
         while inflight:
             drain_one()
-        w.flush()
+        hand_over()
 
 
 class ClipResult:
@@ -784,8 +793,13 @@ _head_cache = {}       # single entry: id(module) -> (weakref to the module, par
 
 def _param_versions(model):
     # torch bumps Tensor._version on every in-place update (optimizer.step, load_state_dict, .copy_): together with
-    # the storage address this fingerprints "the same weights as when the device copy was made"
-    return tuple((p.data_ptr(), p._version) for p in model.state_dict().values())
+    # the storage address this fingerprints "the same weights as when the device copy was made".  Writes through
+    # ``param.data`` use a separate version counter, so a cheap content check rides along: the two scalar parameters
+    # and a slice of every tensor (a few hundred numbers; an update that changes none of them is not a realistic one).
+    sd = model.state_dict()
+    with torch.no_grad():
+        probe = tuple(float(p.detach().reshape(-1)[:32].double().sum()) for p in sd.values())
+    return tuple((p.data_ptr(), p._version) for p in sd.values()) + probe
 
 
 def _as_mi355x_head(model, device) -> ClassifierLSTMDeltas:

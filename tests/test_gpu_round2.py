@@ -191,6 +191,12 @@ def test_infer_file_follows_weight_updates_of_a_reference_module(tmp_path):
         m.lin1.bias.add_(0.5)
     w3 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
     np.testing.assert_allclose(run(m), PO.classify_cls(cls, w3, 31, 1.0), atol=1e-4)
+    m.lin2.bias.data.mul_(-1.0)                                         # a write through .data bumps no version counter
+    m.gate.data.fill_(1.5)
+    w4 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    p4 = run(m)
+    np.testing.assert_allclose(p4, PO.classify_cls(cls, w4, 31, 1.0), atol=1e-4)
+    assert np.abs(p4 - PO.classify_cls(cls, w3, 31, 1.0)).max() > 1e-3
 
 
 def test_fused_session_host_and_device_pushes_equal_two_step_path():
@@ -400,13 +406,18 @@ def test_encode_files_cli_single_process(tmp_path, capsys):
         head.close()
 
 
-def _dist_rank(rank, world, port, td, q):
+def _dist_rank(rank, world, port, td, q, backend="gloo"):
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    local = str(rank) if backend == "nccl" else "0"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=local,
+                      LOCAL_WORLD_SIZE=str(world))
     import torch.distributed as dist
     from cbas_amd import dist as cdist, pipeline as P
     from cbas_amd.head import ClassifierLSTMDeltas
-    cdist.init_from_env("gloo")                       # two ranks share the one GPU of the test box: rows travel through gloo
+    # gloo: two ranks share the one GPU of the test box, rows travel through host memory; nccl: one GPU per rank over RCCL
+    cdist.init_from_env(backend)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
     cfg, enc = _enc("tiny", 16, (64, 64))
     head = ClassifierLSTMDeltas(cfg.hidden_size, 4)
     head.load_state_dict(W.synth_head_weights(C.HeadConfig(in_features=cfg.hidden_size, out_features=4), 3))
@@ -422,9 +433,13 @@ def _dist_rank(rank, world, port, td, q):
     dist.destroy_process_group()
 
 
-def test_encode_files_two_ranks_real_kernels(tmp_path):
-    """Two processes (gloo) driving the real encoder / head on the one GPU: rank 0's files are byte-identical to the
-    single-process encode_file / infer_file results."""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_encode_files_two_ranks_real_kernels(tmp_path, backend):
+    """Two processes driving the real encoder / head: rank 0's files are byte-identical to the single-process encode_file /
+    infer_file results.  gloo: both ranks on the one GPU.  nccl (RCCL over xGMI, device-to-device point-to-point transfers
+    from a receiver thread): needs two GPUs - skipped on the one-GPU test box, so THIS PATH HAS NOT RUN YET."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL path needs two GPUs")
     import hashlib, os, shutil, socket
     import torch.multiprocessing as mp
     from cbas_amd import pipeline as P
@@ -449,7 +464,7 @@ def test_encode_files_two_ranks_real_kernels(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, str(b), q)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, str(b), q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     recs = q.get(timeout=240)
