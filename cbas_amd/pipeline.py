@@ -281,6 +281,19 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
     tmp_file_path = out_file_path + ".tmp"
     D = encoder.config.hidden_size
     nslots = _lib.ENC_SLOTS
+    if _wants_pinned(encoder) and os.environ.get("CBAS_ENCODE_FILE_SLOTS") != "1":
+        # The native encoder: the chunk loop runs inside an encode-only fused session (frames DMA'd from the page-locked
+        # decode-ahead ring, rows collected in HBM, one copy-out) and the file is written in one append at the end -
+        # the same bytes (tests/test_host_logic.py), `.tmp` + rename as ever, +4 % over the per-batch copy-out of the
+        # slot loop below (which stays for stand-in encoders and as CBAS_ENCODE_FILE_SLOTS=1)
+        try:
+            res = _runner_for(encoder, None, 1.0).run(path, reader, progress_callback)
+            out = write_cls_file(path, res.rows, file_attrs(encoder))
+        except Exception as e:
+            print(f"ERROR during encoding for {path}: {e}")
+            raise
+        print(f"Successfully encoded {os.path.basename(path)} to {os.path.basename(out)}")
+        return out
     try:
         with h5io.ClsWriter(tmp_file_path, D, file_attrs(encoder)) as w_sync:
             w = _WriterThread(w_sync)
