@@ -344,3 +344,38 @@ def test_ln_fold_dinov2_and_unsupported_widths(golden_dir):
             enc.debug_option("no_such_option", 1)
     finally:
         enc.close()
+
+
+def test_file_paths_survive_a_workspace_rebuild_and_mixed_clip_sizes(tmp_path):
+    """Frames larger than the encoder's workspace rebuild the handle once (DinoEncoder._fit_frame), which closes the open
+    fused sessions; the cached ClipRunner must notice and carry on.  Then clips of other sizes, shorter and longer than the
+    session's capacity, through the same runner: every result equals the slot loop's (CBAS_ENCODE_FILE_SLOTS=1)."""
+    from cbas_amd import h5io, pipeline as P
+    cfg, enc, head = _tiny(max_batch=16, hw=(32, 32))
+    names = list("abcde")
+    try:
+        def rows_of(p):
+            with h5io.ClsReader(p) as r:
+                return r.read(0, r.shape[0])
+        for i, (n, hw) in enumerate([(40, (32, 32)), (70, (64, 48)), (5000, (32, 32)), (33, (64, 48)), (9, (16, 80))]):
+            d = tmp_path / f"c{i}"
+            d.mkdir()
+            fr = synth.noise_frames(200 + i, n, *hw)
+            np.save(str(d / "v.npy"), fr)
+            h5, csv = P.encode_infer_file(enc, head, str(d / "v.npy"), "m", names)
+            got = rows_of(h5)
+            os.environ["CBAS_ENCODE_FILE_SLOTS"] = "1"
+            try:
+                os.remove(h5)
+                ref = rows_of(P.encode_file(enc, str(d / "v.npy")))
+            finally:
+                del os.environ["CBAS_ENCODE_FILE_SLOTS"]
+            assert got.shape == (n, cfg.hidden_size) and np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (n, hw)
+            fused = rows_of(P.encode_file(enc, str(d / "v.npy")))          # the default encode_file: encode-only session
+            assert np.array_equal(fused.view(np.uint16), ref.view(np.uint16))
+            csv2 = P.infer_file(h5, head, "m2", names, 31, device="cuda")
+            assert open(csv, "rb").read() == open(csv2, "rb").read()
+        assert enc.max_frame[0] >= 64 and enc.max_frame[1] >= 80
+    finally:
+        head.close()
+        enc.close()
