@@ -31,6 +31,8 @@ struct cbas_fused {
     struct Busy { int64_t n = 0; uint64_t seq = 0; } busy[CBAS_ENC_SLOTS];
     int next_slot = 0;
     uint64_t seq = 0;
+    hipEvent_t clip_done = nullptr; // recorded on st when a clip's last operation (tail classify, copy-out) has been queued
+    bool clip_pending = false;
 };
 
 namespace {
@@ -124,6 +126,7 @@ extern "C" int cbas_fused_create(cbas_enc* enc, cbas_head* head, int64_t capacit
         f->st = (hipStream_t)cbas_enc_copy_stream(enc);
         if (!f->st) { e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking); f->own_stream = true; }
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->clip_done, hipEventDisableTiming);
     if (e != hipSuccess) {
         cbas_fail(e == hipErrorOutOfMemory ? CBAS_ENOMEM : CBAS_EHIP, "cbas_fused_create: %s", hipGetErrorString(e));
         cbas_fused_destroy(f);
@@ -138,6 +141,7 @@ extern "C" void cbas_fused_destroy(cbas_fused* f) {
     (void)hipSetDevice(f->device);
     (void)drain(f);
     if (f->st) { (void)hipStreamSynchronize(f->st); if (f->own_stream) (void)hipStreamDestroy(f->st); }
+    if (f->clip_done) (void)hipEventDestroy(f->clip_done);
     if (f->cls16) (void)hipFree(f->cls16);
     if (f->probs) (void)hipFree(f->probs);
     delete f;
@@ -148,7 +152,11 @@ extern "C" int cbas_fused_reset(cbas_fused* f) {
     HIP_TRY(hipSetDevice(f->device));
     int rc = drain(f);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(f->st));       // the previous clip's rows are about to be overwritten
+    // the previous clip's rows are about to be overwritten: wait for THIS session's last clip only - the stream is shared
+    // with the encoder's copies and with other sessions, whose clips may still be draining (two sessions alternate when
+    // clips are pipelined back to back: cbas_amd/pipeline.py ClipRunner)
+    if (f->clip_pending) { HIP_TRY(hipEventSynchronize(f->clip_done)); f->clip_pending = false; }
+    else if (f->encoded > 0) HIP_TRY(hipStreamSynchronize(f->st));          // a clip that was never finished
     f->encoded = f->classified = f->landed = 0;
     return CBAS_OK;
 }
@@ -180,15 +188,13 @@ extern "C" int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* p
     if (cls_f16_dev) *cls_f16_dev = f->cls16;
     if (probs_dev) *probs_dev = f->probs;
     if (n_frames) *n_frames = f->encoded;
-    if (cls_f16_host || probs_host || !stream) {
-        HIP_TRY(hipStreamSynchronize(f->st));                           // host results are complete at return
-    }
-    if (stream) {                                                       // device results: `stream` waits, the host does not
-        hipEvent_t ev;
-        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ev, f->st));
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
-        HIP_TRY(hipEventDestroy(ev));
+    HIP_TRY(hipEventRecord(f->clip_done, f->st));
+    f->clip_pending = true;
+    if (stream) {                                                       // `stream` waits for the results, the host does not
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, f->clip_done, 0));
+    } else {
+        HIP_TRY(hipEventSynchronize(f->clip_done));                     // results are complete at return
+        f->clip_pending = false;
     }
     return CBAS_OK;
 }

@@ -324,37 +324,78 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     clip_seq = [0]
     finished = False
     sends: list = []                                       # work handles of this rank's sends (settled per session)
+
+    def deliver(clip: int, res) -> None:
+        """One finished clip: to the local writers (rank 0) or on its way to rank 0."""
+        if res is None:
+            publish(clip, _ST_EMPTY, 0, False)
+            return
+        n, has_probs = res.frames, res.probs is not None
+        if rank == 0:
+            rows = res.rows.cpu().numpy() if res.on_device else res.rows
+            probs = (res.probs.cpu().numpy() if res.on_device else res.probs) if has_probs else None
+            local_done[clip] = (rows, probs)
+            publish(clip, _ST_OK, n, has_probs)
+            return
+        publish(clip, _ST_OK, n, has_probs)
+        if n:
+            rows = res.rows if nccl else torch.from_numpy(res.rows) if not res.on_device else res.rows.cpu()
+            work = _p2p(dist.isend, rows.contiguous(), 0)
+            probs = None
+            if has_probs:
+                probs = res.probs if nccl else torch.from_numpy(res.probs) if not res.on_device else res.probs.cpu()
+                work += _p2p(dist.isend, probs.contiguous(), 0)
+            res.pending.extend(lambda w=w: _wait_done(w) for w in work)     # before the session is reused
+            sends.append((work, rows, probs))
+            sends[:] = [s_ for s_ in sends if not all(w.is_completed() for w in s_[0])]
+
+    # Clips are pipelined back to back where the results go to HOST memory (rank 0, gloo, one process): clip i+1 is pushed
+    # before clip i's tail - its last batches, the tail classification, the copy-out - is waited for, so the GPU never idles
+    # between clips (a clip's fixed cost was ~8 ms: 10 % of a 2 048-frame clip).  On RCCL ranks > 0 the rows leave from
+    # the session's device buffers instead (two sessions alternate there already).
+    pipelined = not (nccl and rank != 0)
+    if pipelined and runner.native and len(runner._sessions) < 2:
+        runner._sessions.append(None)
+    prev = None                                            # (clip, pending result) of the clip before the current one
     try:
         while True:
             clip = queue_.next()
             if clip is None:
                 break
             try:
-                res = runner.run(paths[clip], None, progress_callback, device_out=nccl and rank != 0)
+                if pipelined:
+                    cur = runner.submit(paths[clip], None, progress_callback)
+                else:
+                    cur = P._PendingClip(runner.run(paths[clip], None, progress_callback, device_out=True), None)
             except Exception as e:  # noqa: BLE001 - the queue survives a bad file (workthreads.py:334-336)
                 print(f"ERROR during encoding for {paths[clip]} on rank {rank}: {e}")
                 publish(clip, _ST_FAILED, 0, False)
                 continue
-            if res is None:
-                publish(clip, _ST_EMPTY, 0, False)
-                continue
-            n, has_probs = res.frames, res.probs is not None
-            if rank == 0:
-                rows = res.rows.cpu().numpy() if res.on_device else res.rows
-                probs = (res.probs.cpu().numpy() if res.on_device else res.probs) if has_probs else None
-                local_done[clip] = (rows, probs)
-                publish(clip, _ST_OK, n, has_probs)
-                continue
-            publish(clip, _ST_OK, n, has_probs)
-            if n:
-                rows = res.rows if nccl else torch.from_numpy(res.rows) if not res.on_device else res.rows.cpu()
-                work = _p2p(dist.isend, rows.contiguous(), 0)
-                if has_probs:
-                    probs = res.probs if nccl else torch.from_numpy(res.probs) if not res.on_device else res.probs.cpu()
-                    work += _p2p(dist.isend, probs.contiguous(), 0)
-                res.pending.extend(lambda w=w: _wait_done(w) for w in work)     # before the session is reused
-                sends.append((work, rows, probs if has_probs else None))
-                sends[:] = [s_ for s_ in sends if not all(w.is_completed() for w in s_[0])]
+            finally:
+                if prev is not None:                       # the clip before: its tail has had a whole clip's time to drain
+                    pc, pp = prev
+                    prev = None
+                    try:
+                        deliver(pc, pp.result())
+                    except Exception as e:  # noqa: BLE001
+                        print(f"ERROR during encoding for {paths[pc]} on rank {rank}: {e}")
+                        publish(pc, _ST_FAILED, 0, False)
+            if cur.done:                                   # nothing queued behind it (stand-in encoder, device outputs): now
+                try:
+                    deliver(clip, cur.result())
+                except Exception as e:  # noqa: BLE001
+                    print(f"ERROR during encoding for {paths[clip]} on rank {rank}: {e}")
+                    publish(clip, _ST_FAILED, 0, False)
+            else:
+                prev = (clip, cur)
+        if prev is not None:
+            pc, pp = prev
+            prev = None
+            try:
+                deliver(pc, pp.result())
+            except Exception as e:  # noqa: BLE001
+                print(f"ERROR during encoding for {paths[pc]} on rank {rank}: {e}")
+                publish(pc, _ST_FAILED, 0, False)
         for work, _r, _p in sends:
             for w in work:
                 _wait_done(w)

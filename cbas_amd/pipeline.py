@@ -528,6 +528,13 @@ class _ChunkStream:
         if k is not None and self._ring is not None:
             self._ring.release(k)
 
+    def detach_ring(self):
+        """Hand the page-locked ring to the caller instead of returning its buffers to the pool on ``close`` (copies out of
+        them may still be in flight: ``ClipRunner.submit``); the caller ``give_back()``s it when they are done."""
+        ring, self._ring = self._ring, None
+        self._tokens.clear()
+        return ring
+
     def close(self):
         """Stop and JOIN the decode-ahead thread (so that the caller may close the reader afterwards)."""
         self._stop.set()
@@ -673,6 +680,25 @@ class ClipRunner:
         ent[0].reset()
         return ent
 
+    def submit(self, path: str, reader=None, progress_callback=None) -> "_PendingClip":
+        """``run`` split in two for back-to-back clips: every frame of the video is pushed and the tail (last batches,
+        tail classification, copy-out into page-locked memory) is QUEUED, not waited for; ``.result()`` of the returned
+        object waits and gives the ClipResult (``None`` for a video without frames).  Call it after the NEXT clip has been
+        submitted (sessions alternate: needs ``sessions >= 2``) and the GPU never idles between clips."""
+        if not self.native or len(self._sessions) < 2:
+            return _PendingClip(self.run(path, reader, progress_callback), None)
+        own_reader = reader is None
+        reader = reader if reader is not None else open_video(path)
+        try:
+            video_len = len(reader)
+            if video_len == 0:
+                print(f"Warning: Video {path} contains no frames. Skipping.")
+                return _PendingClip(None, None)
+            return self._run_native(reader, video_len, progress_callback, False, wait=False)
+        finally:
+            if own_reader and hasattr(reader, "close"):
+                reader.close()
+
     def run(self, path: str, reader=None, progress_callback=None, device_out: bool = False) -> Optional[ClipResult]:
         """Encode (and classify) one video; ``None`` for a video without frames.  Reader / encoder errors propagate with
         the encoder left reusable."""
@@ -696,7 +722,7 @@ class ClipRunner:
             if own_reader and hasattr(reader, "close"):
                 reader.close()
 
-    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool) -> ClipResult:
+    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool, wait: bool = True):
         enc = self.encoder
         ent = None
         sub = 0                                      # sub-batches submitted so far
@@ -717,6 +743,13 @@ class ClipRunner:
                 while held and held[0][1] <= sub:
                     chunks.release(held.popleft()[0])
             sess = ent[0]
+            if not wait:
+                # the ring buffers this clip still reads from are released when its last copies are known to be done:
+                # the pending result does that (it is resolved one clip later, with the ring long since given back, so
+                # the buffers go back to the process-wide pool rather than to this stream's ring)
+                rows, probs, ev = sess.finish_host_async()
+                res = ClipResult(rows, probs if self.head is not None else None, False)
+                return _PendingClip(res, ev, chunks.detach_ring())
             if device_out:
                 rows, probs = sess.finish()
                 torch.cuda.current_stream(enc.device).synchronize()      # every copy out of the ring has completed
@@ -727,6 +760,27 @@ class ClipRunner:
             while held:
                 chunks.release(held.popleft()[0])
         return res
+
+
+class _PendingClip:
+    """What ``ClipRunner.submit`` returns: ``result()`` waits for the clip's queued tail and hands out its ClipResult."""
+
+    def __init__(self, res: Optional[ClipResult], event, ring=None):
+        self._res, self._ev, self._ring = res, event, ring
+
+    @property
+    def done(self) -> bool:
+        """Nothing is queued behind this result (``result()`` will not wait)."""
+        return self._ev is None
+
+    def result(self) -> Optional[ClipResult]:
+        if self._ev is not None:
+            self._ev.synchronize()                 # tail classified, rows copied out: every copy out of the ring is long done
+            self._ev = None
+        if self._ring is not None:
+            self._ring.give_back()
+            self._ring = None
+        return self._res
 
 
 _runner_cache: dict = {}

@@ -114,6 +114,22 @@ class ClipStream:
                    "cbas_fused_finish")
         return self._views(p16, pp, int(n.value))
 
+    def finish_host_async(self):
+        """``finish_host`` without blocking: the tail classification and the copy-out are queued, and the call returns
+        (cls_f16, probs, event) - page-locked numpy arrays that are complete once ``event.synchronize()`` has returned.
+        The next clip can be pushed through ANOTHER session meanwhile (this session's buffers are in use until then)."""
+        D, Cn = self.enc.config.hidden_size, (self.head.out_features if self.head is not None else 0)
+        o16 = torch.empty((self.encoded, D), dtype=torch.float16, pin_memory=True).numpy()
+        opr = torch.empty((self.encoded, Cn), dtype=torch.float32, pin_memory=True).numpy() if Cn else np.empty((self.encoded, 0), np.float32)
+        n = C.c_int64(0)
+        ts = torch.cuda.current_stream(self.enc.device)
+        _lib.check(self._lib.cbas_fused_finish(self._h, o16.ctypes.data, opr.ctypes.data if Cn else None, None, None,
+                                               C.byref(n), ts.cuda_stream), "cbas_fused_finish")
+        assert int(n.value) == self.encoded
+        ev = torch.cuda.Event()
+        ev.record(ts)
+        return o16, opr, ev
+
     def finish_host(self) -> Tuple[np.ndarray, np.ndarray]:
         """Classify the tail and copy the clip out: (cls_f16 (N,D) float16, probs (N,C) float32) numpy arrays."""
         D, Cn = self.enc.config.hidden_size, (self.head.out_features if self.head is not None else 0)

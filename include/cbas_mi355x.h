@@ -297,10 +297,11 @@ int cbas_fused_push_u8_host(cbas_fused* f, const uint8_t* frames_host, int n, in
  * valid until the clip is finished. */
 int cbas_fused_push_u8(cbas_fused* f, const uint8_t* frames_dev, int n, int height, int width,
                        int64_t frame_stride, int64_t row_stride, int64_t pixel_stride, void* after_stream);
-/* Classify the tail and hand out the clip: any of cls_f16_host (N x D halves), probs_host (N x C floats) are
- * filled (the call then blocks until they are complete); cls_f16_dev / probs_dev receive the session's device
- * buffers (valid until the next reset / push) and, when `stream` is not NULL, that stream is made to wait for
- * them instead of the host.  n_frames receives N. */
+/* Classify the tail and hand out the clip: any of cls_f16_host (N x D halves), probs_host (N x C floats) are filled;
+ * cls_f16_dev / probs_dev receive the session's device buffers (valid until the next reset / push).  n_frames receives N.
+ * stream == NULL: the call blocks until every output is complete.  stream != NULL: the host is NOT blocked - `stream` is
+ * made to wait for the outputs instead (host buffers, which should then be page-locked, are complete when `stream` reaches
+ * that point: record an event there and wait for it); the next clip may be pushed through another session meanwhile. */
 int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev,
                       const float** probs_dev, int64_t* n_frames, void* stream);
 
