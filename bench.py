@@ -143,13 +143,27 @@ def files_pass(args, enc, head, rank: int, world: int, device) -> dict:
     os.makedirs(root, exist_ok=True)
     n, hw = args.clip_frames, args.hw
     gen = torch.Generator(device=device)
+    avi = args.clip_format == "avi"
+    jpeg_bytes = 0
     for j in range(args.files):
         gen.manual_seed(7000 + rank * 100 + j)
-        fr = torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, device=device, generator=gen).cpu().numpy()
-        np.save(os.path.join(root, f"clip_r{rank:02d}_{j:02d}.npy"), fr)
+        if avi:
+            # camera-like pictures (a smooth field + sensor noise, grey on all three channels), coded 4:2:0 at quality 85
+            from cbas_amd.framesource import write_mjpeg_avi
+            low = torch.rand((n, 1, hw // 16, hw // 16), device=device, generator=gen)
+            g = torch.nn.functional.interpolate(low, size=(hw, hw), mode="bicubic", align_corners=False) * 200.0 + 28.0
+            g = g + torch.randn((n, 1, hw, hw), device=device, generator=gen) * 4.0
+            g8 = g.clamp_(0, 255).to(torch.uint8)[:, 0]
+            fr = g8[..., None].expand(n, hw, hw, 3).contiguous().cpu().numpy()
+            path = os.path.join(root, f"clip_r{rank:02d}_{j:02d}.avi")
+            write_mjpeg_avi(path, fr, quality=85, subsampling=2)
+            jpeg_bytes += os.path.getsize(path)
+        else:
+            fr = torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, device=device, generator=gen).cpu().numpy()
+            np.save(os.path.join(root, f"clip_r{rank:02d}_{j:02d}.npy"), fr)
         del fr
     cdist.barrier()
-    paths = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith(".npy"))
+    paths = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith(".avi" if avi else ".npy"))
     P.set_project_stamp("bench/synthetic-" + args.model)
     try:
         def once():
@@ -171,9 +185,12 @@ def files_pass(args, enc, head, rank: int, world: int, device) -> dict:
         out = {"value": round(frames / dt, 2), "unit": "frames/s", "clips": len(paths), "clips_ok": len(ok),
                "frames_per_clip": n, "seconds": round(dt, 4), "clips_per_rank": per_rank,
                "bytes_written": int(sum(os.path.getsize(r["cls_file"]) + os.path.getsize(r["csv_file"]) for r in ok)),
-               "what": "cbas_amd.dist.encode_files over synthetic .npy clips (page cache -> page-locked ring -> HBM -> fused "
-                       "encode + classify -> gather to rank 0 -> _cls.h5 + _outputs.csv on rank 0's writer threads); "
-                       "barrier to barrier, second pass"}
+               "what": "cbas_amd.dist.encode_files over synthetic " +
+                       ("Motion-JPEG AVI clips (4:2:0, quality 85, %.1f KB per frame; decoded by cbas_mjpeg_decode on host "
+                        "threads -> green planes in the page-locked ring" % (jpeg_bytes / 1024.0 / max(1, n * args.files)) if avi else
+                        ".npy clips (page cache -> page-locked ring") +
+                       " -> HBM -> fused encode + classify -> gather to rank 0 -> _cls.h5 + _outputs.csv on rank 0's writer "
+                       "threads); barrier to barrier, second pass"}
     cdist.barrier()
     if rank == 0 and args.files_dir is None:
         shutil.rmtree(root, ignore_errors=True)
@@ -197,6 +214,8 @@ def main() -> None:
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (compute lanes of the encoder)")
     ap.add_argument("--files", type=int, default=2, help="clips per rank of the files_path pass (0: skip it)")
     ap.add_argument("--clip-frames", type=int, default=4096, help="frames per clip of the files_path pass")
+    ap.add_argument("--clip-format", choices=("npy", "avi"), default="npy",
+                    help="files_path clips: raw uint8 frames (.npy) or Motion-JPEG AVI (real decoder work in the loop)")
     ap.add_argument("--files-dir", default=None, help="where the synthetic clips go (default: a temp dir under /dev/shm)")
     args = ap.parse_args()
 

@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libcbas_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["gemm_f16.hip", "gemm_f16_8ph.hip", "gemm_f16_skinny.hip", "gemm_f32.hip", "vit_kernels.hip", "head_kernels.hip", "head_train_kernels.hip",
-           "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip", "host_text.cpp"]
+           "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip", "host_text.cpp", "host_mjpeg.cpp"]
+EXTRA_FLAGS = {"host_mjpeg.cpp": ["-mavx2"]}      # host-only file: 8-lane integer vectors in the inverse DCT (checked at run time)
 ARCH = "gfx950"
 
 
@@ -52,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
                 and all(os.path.getmtime(obj) > os.path.getmtime(hp) for hp in headers)):
             continue
-        cmd = [hipcc, *common, "-c", srcp, "-o", obj]
+        cmd = [hipcc, *common, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

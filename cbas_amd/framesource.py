@@ -17,6 +17,7 @@ that layout directly (50 KB per 224x224 frame over PCIe instead of 150 KB).
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import queue
 import subprocess
@@ -276,16 +277,22 @@ def _riff_chunks(buf, start: int, end: int):
 
 
 class MJPEGAviSource:
-    """``decord.VideoReader``-shaped reader (``len``, ``get_batch(indices)`` -> (n, H, W, 3) uint8 RGB) for Motion-JPEG AVI
-    files.  The file is memory-mapped, the frame table comes from walking the ``movi`` list(s) once, and frames are decoded
-    by Pillow on a small thread pool (its JPEG decoder releases the GIL), straight into the caller's buffer when
-    ``read_into`` is used - which is what the decode-ahead thread of ``pipeline._ChunkStream`` does with its page-locked
-    ring buffers.  Decoded pixels are libjpeg-turbo's (ISLOW DCT, fancy upsampling); whether ffmpeg's MJPEG decoder +
-    swscale, which decord would use, produces the same green plane bit for bit is NOT verified in this environment."""
+    """``decord.VideoReader``-shaped reader (``len``, ``get_batch(indices)``) for Motion-JPEG AVI files.  The file is
+    memory-mapped, the frame table comes from walking the ``movi`` list(s) once, and frames are decoded by the library's own
+    decoder (``cbas_mjpeg_decode``, include/cbas_mi355x.h: C++ threads, no GIL, pixel-identical to Pillow's libjpeg-turbo)
+    straight into the caller's buffer when ``read_into`` is used - which is what the decode-ahead thread of
+    ``pipeline._ChunkStream`` does with its page-locked ring buffers.  ``planes=True`` delivers the green plane only,
+    (n, H, W) - the one channel the encoder reads (backend/cbas.py:431), a third of the host writes and PCIe bytes;
+    ``planes=False`` the (n, H, W, 3) RGB frames decord would.  Streams the native decoder refuses (progressive, CMYK,
+    exotic sampling) and builds without the library go through Pillow on a thread pool instead.  Whether ffmpeg's MJPEG
+    decoder + swscale, which decord would use, produces the same green plane bit for bit is NOT verified here."""
 
-    def __init__(self, path: str, threads: int = 8):
+    def __init__(self, path: str, threads: Optional[int] = None, planes: bool = False, native: Optional[bool] = None):
         import mmap
         self.path = path
+        self.planes = bool(planes)
+        self._native = native                    # None: try the library, fall back to Pillow; True: library or raise; False: Pillow
+        self._table = None
         self._f = open(path, "rb")
         self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
         mm = self._mm
@@ -319,8 +326,8 @@ class MJPEGAviSource:
             pos = rend + (rsize & 1)
         if self._frames and not (self.width and self.height):
             self.height, self.width = self._decode(0).shape[:2]
-        self.frame_shape = (self.height, self.width, 3)
-        self._threads = max(1, int(threads))
+        self.frame_shape = (self.height, self.width) if self.planes else (self.height, self.width, 3)
+        self._threads = max(1, int(threads)) if threads else max(1, min(16, (os.cpu_count() or 4) - 2))
         self._pool = None
 
     def _walk_movi(self, start: int, end: int) -> None:
@@ -348,22 +355,69 @@ class MJPEGAviSource:
             self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix="cbas-mjpeg")
         return self._pool
 
+    def _frame_table(self):
+        """(offsets, sizes) as the native decoder takes them; a zero-length chunk stands for the frame before it."""
+        if self._table is None:
+            off = np.array([f[0] for f in self._frames], np.uint64)
+            size = np.array([f[1] for f in self._frames], np.uint32)
+            src = np.arange(len(size))
+            src[size == 0] = 0
+            src = np.maximum.accumulate(src)          # index of the last non-empty chunk at or before each frame
+            self._table = (np.ascontiguousarray(off[src]), np.ascontiguousarray(size[src]))
+        return self._table
+
+    def _native_decode(self, idx: np.ndarray, out: np.ndarray) -> bool:
+        """Decode frames ``idx`` into ``out`` with the library; False when it is not available or refuses the stream."""
+        if self._native is False:
+            return False
+        try:
+            from . import _lib
+            lib = _lib.load()
+        except Exception:  # noqa: BLE001 - no library in this environment
+            if self._native:
+                raise
+            self._native = False
+            return False
+        off, size = self._frame_table()
+        off, size = np.ascontiguousarray(off[idx]), np.ascontiguousarray(size[idx])
+        base = np.frombuffer(self._mm, np.uint8)
+        bad = ctypes.c_int32(-1)
+        rc = lib.cbas_mjpeg_decode(base.ctypes.data, off.ctypes.data, size.ctypes.data, len(idx), self.height, self.width,
+                                   1 if self.planes else 3, out.ctypes.data, self._threads, ctypes.byref(bad))
+        del base
+        if rc == 0:
+            return True
+        why = lib.cbas_last_error().decode(errors="replace")
+        if self._native or "unsupported" not in why:
+            raise ValueError(f"{self.path}: {why}")
+        self._native = False                     # a stream outside the native decoder's envelope: Pillow from here on
+        return False
+
     def read_into(self, start: int, stop: int, out: np.ndarray) -> None:
+        if tuple(out.shape[1:]) != self.frame_shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError(f"{self.path}: read_into needs a C-contiguous uint8 (n,) + {self.frame_shape} buffer")
+        if self._native_decode(np.arange(start, stop), out):
+            return
+
         def one(k):
             fr = self._decode(start + k)
-            if fr.shape != out.shape[1:]:
+            if fr.shape[:2] != out.shape[1:3]:
                 raise ValueError(f"{self.path}: frame {start + k} is {fr.shape}, the stream header says {out.shape[1:]}")
-            np.copyto(out[k], fr)
+            np.copyto(out[k], fr[:, :, 1] if self.planes else fr)
         list(self._executor().map(one, range(stop - start)))
 
     def get_batch(self, indices) -> np.ndarray:
         idx = list(indices)
         out = np.empty((len(idx),) + self.frame_shape, np.uint8)
-        if idx and idx == list(range(idx[0], idx[0] + len(idx))):
+        if not idx:
+            return out
+        idx = [i + len(self._frames) if i < 0 else i for i in idx]
+        if idx == list(range(idx[0], idx[0] + len(idx))):
             self.read_into(idx[0], idx[0] + len(idx), out)
-        else:
+        elif not self._native_decode(np.asarray(idx, np.int64), out):
             for k, i in enumerate(idx):
-                out[k] = self._decode(i)
+                fr = self._decode(i)
+                out[k] = fr[:, :, 1] if self.planes else fr
         return out
 
     def close(self):
@@ -386,10 +440,11 @@ class MJPEGAviSource:
             pass
 
 
-def write_mjpeg_avi(path: str, frames: np.ndarray, fps: int = 10, quality: int = 90) -> None:
+def write_mjpeg_avi(path: str, frames: np.ndarray, fps: int = 10, quality: int = 90, subsampling: Optional[int] = None) -> None:
     """Write uint8 (N, H, W, 3) RGB (or (N, H, W) grey) frames as a Motion-JPEG AVI (one stream, ``idx1`` index): test and
     benchmark clips that any player / ffmpeg / decord opens.  JPEG is lossy: the decoded frames are the reference point,
-    not ``frames``."""
+    not ``frames``.  ``subsampling``: Pillow's 0 / 1 / 2 = 4:4:4 (the default for RGB input) / 4:2:2 / 4:2:0 (what cameras
+    and ffmpeg's mjpeg encoder write)."""
     import io
     import struct
     from PIL import Image
@@ -398,7 +453,10 @@ def write_mjpeg_avi(path: str, frames: np.ndarray, fps: int = 10, quality: int =
     jpegs = []
     for i in range(n):
         b = io.BytesIO()
-        Image.fromarray(frames[i]).save(b, format="JPEG", quality=quality, subsampling=0 if frames.ndim == 4 else None)
+        if frames.ndim == 4:
+            Image.fromarray(frames[i]).save(b, format="JPEG", quality=quality, subsampling=0 if subsampling is None else subsampling)
+        else:
+            Image.fromarray(frames[i]).save(b, format="JPEG", quality=quality)
         jpegs.append(b.getvalue())
 
     def chunk(cc: bytes, data: bytes) -> bytes:

@@ -155,9 +155,9 @@ def open_video(path: str):
     try:
         r = _DecordSource(path)
     except ImportError as e:
-        if ext == ".avi":                            # Motion-JPEG AVI decodes in-process (Pillow); anything else falls through
+        if ext == ".avi":                            # Motion-JPEG AVI decodes in-process (cbas_mjpeg_decode); anything else falls through
             try:
-                return MJPEGAviSource(path)
+                return MJPEGAviSource(path, planes=True)
             except ValueError:
                 pass
         if shutil.which("ffmpeg") and shutil.which("ffprobe"):

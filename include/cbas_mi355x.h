@@ -51,7 +51,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   7
+#define CBAS_ABI_VERSION   8
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -356,6 +356,19 @@ int cbas_head_train_last_outputs(cbas_head_trainer* t, float* logits_host, float
 int64_t cbas_csv_format_f32(const float* values_host, int64_t n_rows, int32_t n_cols, char* out, int64_t cap);
 int cbas_csv_write_f32(const char* path, const char* header_line, const float* values_host, int64_t n_rows,
                        int32_t n_cols, int32_t n_threads);
+
+/* ---- frame source: Motion-JPEG decode ---------------------------------------------------------
+ * The reference reads frames with decord.VideoReader(path, ctx=cpu(0)).get_batch(range(i, end)).asnumpy()
+ * (backend/cbas.py:402,425) and keeps channel 1 (:431).  For Motion-JPEG streams this call is that decoder: frame k is the
+ * JPEG at data[offsets[k] .. offsets[k] + sizes[k]); every frame must be height x width; channels = 1 writes the green
+ * plane (n, H, W), channels = 3 the RGB frame (n, H, W, 3) - into `out` (host memory, e.g. a page-locked ring piece),
+ * on up to n_threads threads.  Baseline / extended-sequential Huffman JPEG, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
+ * restart intervals, Annex K tables when a frame has no DHT; pixel-identical to libjpeg-turbo's default decode (islow
+ * IDCT, fancy upsampling).  Returns CBAS_EINVAL for a frame it cannot decode (cbas_last_error says whether the stream is
+ * corrupt or "unsupported: ..."), with the index of the first such frame in *bad_frame (may be NULL). */
+int cbas_mjpeg_decode(const uint8_t* data, const uint64_t* offsets, const uint32_t* sizes, int32_t n_frames,
+                      int32_t height, int32_t width, int32_t channels, uint8_t* out, int32_t n_threads,
+                      int32_t* bad_frame);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 

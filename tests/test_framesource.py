@@ -138,29 +138,37 @@ def test_decode_ahead_overlaps_and_preserves_order_and_errors():
 
 
 def test_mjpeg_avi_round_trip_and_decode_ahead(tmp_path):
-    """A real compressed video through the reader interface encode_file uses: Motion-JPEG AVI written here, decoded by
-    Pillow's libjpeg-turbo.  Frame count, shape, random and sequential access, read_into == get_batch, dropped-frame
-    chunks, and the decode-ahead stream delivers exactly the reader's frames."""
+    """A real compressed video through the reader interface encode_file uses: Motion-JPEG AVI written here, decoded by the
+    library's own decoder (green planes, what open_video asks for) and by Pillow.  Frame count, shape, random and
+    sequential access, read_into == get_batch, and the decode-ahead stream delivers exactly the reader's frames."""
     from cbas_amd import framesource as F, pipeline as P, synth
     fr = synth.cage_frames(2, 70, 48, 64)
     p = str(tmp_path / "clip.avi")
     F.write_mjpeg_avi(p, fr, fps=10, quality=95)
-    r = P.open_video(p)                                      # no decord here -> the in-process MJPEG reader
-    assert isinstance(r, F.MJPEGAviSource) and len(r) == 70 and r.frame_shape == (48, 64, 3)
-    allf = r.get_batch(range(70))
+    r = P.open_video(p)                                      # no decord here -> the in-process MJPEG reader, green planes
+    assert isinstance(r, F.MJPEGAviSource) and len(r) == 70 and r.frame_shape == (48, 64)
+    rgb = F.MJPEGAviSource(p)                                # decord-shaped: RGB frames
+    assert rgb.frame_shape == (48, 64, 3)
+    allf = rgb.get_batch(range(70))
     assert allf.shape == (70, 48, 64, 3) and allf.dtype == np.uint8
     assert np.abs(allf.astype(int) - fr.astype(int)).mean() < 6.0          # lossy, but the same pictures
-    assert np.array_equal(r.get_batch([3, 69, 0]), allf[[3, 69, 0]])
-    out = np.empty((20, 48, 64, 3), np.uint8)
+    assert np.array_equal(rgb.get_batch([3, 69, 0]), allf[[3, 69, 0]]) and np.array_equal(rgb.get_batch([-1]), allf[69:])
+    planes = r.get_batch(range(70))
+    assert planes.shape == (70, 48, 64) and np.array_equal(planes, allf[..., 1])     # channel 1 (backend/cbas.py:431)
+    out = np.empty((20, 48, 64), np.uint8)
     r.read_into(10, 30, out)
-    assert np.array_equal(out, allf[10:30])
+    assert np.array_equal(out, planes[10:30])
+    with pytest.raises(ValueError, match="read_into needs"):
+        r.read_into(0, 4, np.empty((4, 48, 64, 3), np.uint8))
     got = [f.copy() for _i, _e, f in P._chunks(r, len(r), piece=32)]
-    assert [g.shape[0] for g in got] == [32, 32, 6] and np.array_equal(np.concatenate(got), allf)
+    assert [g.shape[0] for g in got] == [32, 32, 6] and np.array_equal(np.concatenate(got), planes)
     r.close()
-    # decoding is deterministic (same bytes -> same pixels), so embeddings of a file are reproducible
-    r2 = F.MJPEGAviSource(p, threads=1)
-    assert np.array_equal(r2.get_batch(range(70)), allf)
-    r2.close()
+    rgb.close()
+    # decoding is deterministic and the two decoders agree bit for bit: same bytes -> same pixels, whichever ran
+    for kw in ({"threads": 1}, {"native": False}, {"native": True, "threads": 3}):
+        r2 = F.MJPEGAviSource(p, **kw)
+        assert np.array_equal(r2.get_batch(range(70)), allf), kw
+        r2.close()
     # not Motion-JPEG -> refused (open_video then goes on to the ffmpeg pipe, or reports that nothing can read it)
     raw = bytearray(open(p, "rb").read())
     i = raw.find(b"vidsMJPG")
