@@ -32,7 +32,7 @@ struct cbas_head_trainer {
     cbas_head_config cfg;
     cbas_train_config tcfg;
     int device = 0;
-    int I, C, T, Bn, L0, h, NL, lo, hi, NPROJ, F, H2;
+    int I, C, T, Bn, L0, h, NL, lo, hi, NPROJ, F, H2, NS;
     int64_t n_blob = 0, n_train = 0;
     std::vector<MapEntry> map;
     // segment offsets (floats) in the train layout
@@ -83,8 +83,10 @@ int build_layout(cbas_head_trainer* t) {
     int64_t o = 0;
     auto seg = [&](int64_t n) { const int64_t at = o; o += pad4(n); return at; };
     t->o_wproj = seg((int64_t)t->NPROJ * I);
-    t->o_bbott = seg(3 * Bn); t->o_lnw = seg(3 * Bn); t->o_lnb = seg(3 * Bn); t->o_blin1 = seg(C);
-    t->o_wlin0 = seg(L0 * 3 * Bn); t->o_blin0 = seg(L0);
+    const int64_t NS = t->NS;
+    // b_bott | ln_w | ln_b must be contiguous (one column sum over part_exp fills all three gradients): NS * Bn is a multiple of 4
+    t->o_bbott = seg(NS * Bn); t->o_lnw = seg(NS * Bn); t->o_lnb = seg(NS * Bn); t->o_blin1 = seg(C);
+    t->o_wlin0 = seg(L0 * NS * Bn); t->o_blin0 = seg(L0);
     for (int l = 0; l < t->NL; ++l) {
         const int64_t in = l == 0 ? L0 : 2 * h;
         t->o_wih[l] = seg(8 * h * in); t->o_bih[l] = seg(8 * h); t->o_bhh[l] = seg(8 * h); t->o_whh[l] = seg(8 * h * h);
@@ -96,10 +98,10 @@ int build_layout(cbas_head_trainer* t) {
     int64_t b = 0;
     auto put = [&](int64_t train_off, int64_t n) { t->map.push_back({b, train_off, n}); b += n; };
     put(t->o_gate, 1); put(t->o_temp, 1);
-    for (int s = 0; s < 3; ++s) { put(t->o_wproj + s * Bn * I, Bn * I); put(t->o_bbott + s * Bn, Bn); }
-    for (int s = 0; s < 3; ++s) { put(t->o_lnw + s * Bn, Bn); put(t->o_lnb + s * Bn, Bn); }
-    put(t->o_wlin0, L0 * 3 * Bn); put(t->o_blin0, L0);
-    put(t->o_wproj + 3 * Bn * I, C * I); put(t->o_blin1, C);
+    for (int s = 0; s < NS; ++s) { put(t->o_wproj + s * Bn * I, Bn * I); put(t->o_bbott + s * Bn, Bn); }
+    for (int s = 0; s < NS; ++s) { put(t->o_lnw + s * Bn, Bn); put(t->o_lnb + s * Bn, Bn); }
+    put(t->o_wlin0, L0 * NS * Bn); put(t->o_blin0, L0);
+    put(t->o_wproj + NS * Bn * I, C * I); put(t->o_blin1, C);
     for (int l = 0; l < t->NL; ++l) {
         const int64_t in = l == 0 ? L0 : 2 * h;
         for (int dir = 0; dir < 2; ++dir) {
@@ -161,8 +163,8 @@ extern "C" int cbas_head_train_create(const cbas_head_config* cfg, const cbas_tr
     if (c.out_features <= 0 || c.out_features > 64) return cbas_fail(CBAS_EINVAL, "out_features=%d outside [1,64]", c.out_features);
     if (c.bottleneck_dim % 64 || c.bottleneck_dim <= 0 || c.bottleneck_dim > 256) return cbas_fail(CBAS_EINVAL, "bottleneck_dim=%d unsupported", c.bottleneck_dim);
     if (c.lin0_dim % 32 || c.lin0_dim <= 0) return cbas_fail(CBAS_EINVAL, "lin0_dim=%d must be a multiple of 32", c.lin0_dim);
-    if (!c.use_acceleration) return cbas_fail(CBAS_EINVAL, "training needs use_acceleration = 1 (three bottleneck streams)");
-    if (c.lstm_hidden_size != 64 && c.lstm_hidden_size != 128) return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%d: only 64 and 128 are built", c.lstm_hidden_size);
+    if (c.lstm_hidden_size < 16 || c.lstm_hidden_size > 128 || c.lstm_hidden_size % 16)
+        return cbas_fail(CBAS_EINVAL, "lstm_hidden_size=%d: multiples of 16 from 16 to 128 are built", c.lstm_hidden_size);
     if (c.seq_len < 3 || c.seq_len > 101) return cbas_fail(CBAS_EINVAL, "seq_len=%d outside [3,101]", c.seq_len);
     if (c.lstm_layers < 1 || c.lstm_layers > 4) return cbas_fail(CBAS_EINVAL, "lstm_layers=%d outside [1,4]", c.lstm_layers);
     if (tcfg->max_batch < 1 || tcfg->max_batch > 65536) return cbas_fail(CBAS_EINVAL, "max_batch=%d outside [1,65536]", tcfg->max_batch);
@@ -179,8 +181,9 @@ extern "C" int cbas_head_train_create(const cbas_head_config* cfg, const cbas_tr
     if (!t) return cbas_fail(CBAS_ENOMEM, "out of host memory");
     t->cfg = c; t->tcfg = *tcfg; t->device = device_id;
     t->I = c.in_features; t->C = c.out_features; t->T = T; t->Bn = c.bottleneck_dim; t->L0 = c.lin0_dim; t->h = c.lstm_hidden_size;
-    t->NL = c.lstm_layers; t->lo = lo; t->hi = hi; t->F = 3 * t->Bn; t->H2 = 2 * t->h;
-    t->NPROJ = (int)round_up(3 * t->Bn + t->C, 4);
+    t->NS = c.use_acceleration ? 3 : 2;                        // bottleneck streams (classifier_head.py:74-84)
+    t->NL = c.lstm_layers; t->lo = lo; t->hi = hi; t->F = t->NS * t->Bn; t->H2 = 2 * t->h;
+    t->NPROJ = (int)round_up(t->F + t->C, 4);
     build_layout(t);
     if (t->n_blob != n_weights) { delete t; return cbas_fail(CBAS_EINVAL, "internal blob layout mismatch"); }
     if (train_expand_lds_bytes(T, t->Bn, t->NPROJ) > 160 * 1024) {
@@ -275,7 +278,7 @@ extern "C" int cbas_head_train_step(cbas_head_trainer* t, const float* x_dev, co
     LAUNCH_TRY(gemm_nt(x_dev, I, P + t->o_wproj, NP, nullptr, t->proj, NP, R, NP, I, st));
     TrainExpandParams ep{};
     ep.proj = t->proj; ep.tmat = t->tmat; ep.lin_vec = t->lin_vec; ep.b_bott = P + t->o_bbott; ep.ln_w = P + t->o_lnw;
-    ep.ln_b = P + t->o_lnb; ep.b_lin1 = P + t->o_blin1; ep.T = T; ep.Bn = Bn; ep.NPROJ = NP; ep.C = C;
+    ep.ln_b = P + t->o_lnb; ep.b_lin1 = P + t->o_blin1; ep.T = T; ep.Bn = Bn; ep.NPROJ = NP; ep.C = C; ep.NS = t->NS;
     for (int s = 0; s < 3; ++s) ep.key[s] = key[s];
     ep.thr = thr_b; ep.scale = sc_b;
     LAUNCH_TRY(launch_train_expand_fwd(ep, B, t->Y, t->aug, t->lin_logits, st));

@@ -83,6 +83,7 @@ struct ExpandArgs {
     const float* ln_b;       // [3 Bn]
     const float* b_lin1;     // [C]
     int T, Bn, NPROJ, C;
+    int NS;                  // bottleneck streams: 3 (cls | delta | acc) or 2 (use_acceleration = False, classifier_head.py:74-84)
     int big;                 // long windows (seq_len 63 / 95: sweep_runner.py:110): only U lives in LDS, the projected rows
                              // and the temporal matrices are read from global memory (same fma order: same bits)
     unsigned long long key[3];
@@ -92,7 +93,7 @@ struct ExpandArgs {
 __global__ __launch_bounds__(768) void train_expand_fwd_kernel(ExpandArgs a, float* __restrict__ Y, float* __restrict__ aug,
                                                                float* __restrict__ lin_logits) {
     extern __shared__ float sm[];
-    const int T = a.T, Bn = a.Bn, F = 3 * Bn, NP = a.NPROJ;
+    const int T = a.T, Bn = a.Bn, NS = a.NS, F = NS * Bn, NP = a.NPROJ;
     const int64_t w = blockIdx.x;
     const int tid = threadIdx.x;
     const float* P;                      // [T][NP]
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(768) void train_expand_fwd_kernel(ExpandArgs a, flo
     __syncthreads();
     // LayerNorm of each (t, k) row of Bn values: one wave per row, two-pass statistics
     const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    for (int row = wave; row < 3 * T; row += nw) {
-        const int t = row / 3, k = row - t * 3;
+    for (int row = wave; row < NS * T; row += nw) {
+        const int t = row / NS, k = row - t * NS;
         const float* u = U + t * F + k * Bn;
         float s = 0.f;
         for (int c = lane; c < Bn; c += 64) s += u[c];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
                                                                const float* __restrict__ daug, const float* __restrict__ dlin,
                                                                float* __restrict__ dproj, float* __restrict__ part) {
     extern __shared__ float sm[];
-    const int T = a.T, Bn = a.Bn, F = 3 * Bn, NP = a.NPROJ;
+    const int T = a.T, Bn = a.Bn, NS = a.NS, F = NS * Bn, NP = a.NPROJ;
     const int64_t w = blockIdx.x;
     const int tid = threadIdx.x;
     const float* TM;                     // [3][T][T]
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
         for (int i = tid; i < 3 * T * T; i += blockDim.x) TMl[i] = a.tmat[i];
         TM = TMl;
     }
-    float* ST = U + T * F;               // [3T][4]  mean, rstd, sum(dxhat)/Bn, sum(dxhat*xhat)/Bn
+    float* ST = U + T * F;               // [NS T][4]  mean, rstd, sum(dxhat)/Bn, sum(dxhat*xhat)/Bn
     const int k = tid < F ? tid / Bn : 0;
     if (tid < F) {
         for (int t = 0; t < T; ++t) {
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    for (int row = wave; row < 3 * T; row += nw) {
-        const int t = row / 3, kk = row - t * 3;
+    for (int row = wave; row < NS * T; row += nw) {
+        const int t = row / NS, kk = row - t * NS;
         const float* u = U + t * F + kk * Bn;
         float s = 0.f;
         for (int c = lane; c < Bn; c += 64) s += u[c];
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
         float dgam = 0.f, dbet = 0.f, dbias = 0.f;
         // dY[t] overwrites this thread's column of U (only this thread touches it from here on)
         for (int t = 0; t < T; ++t) {
-            const float* st = ST + (t * 3 + k) * 4;
+            const float* st = ST + (t * NS + k) * 4;
             const float xhat = (U[t * F + tid] - st[0]) * st[1];
             const float dy = daug[(w * T + t) * F + tid];
             dgam += dy * xhat;
@@ -352,10 +353,11 @@ __global__ __launch_bounds__(256) void pool_train_fwd_kernel(PoolArgs a, float* 
     __shared__ float lat[256];
     const int64_t w = blockIdx.x;
     const int u = threadIdx.x, nwv = blockDim.x >> 6, nc = a.hi - a.lo;
+    const bool live = u < a.H2;                  // the block is 2h rounded up to whole waves
     const float temp = softplus_temp(a.att_temp[0]);
-    const float wa = a.w_att[u];
+    const float wa = live ? a.w_att[u] : 0.f;
     for (int t = 0; t < nc; ++t) {
-        const float s = block_sum(a.hout[(w * a.T + a.lo + t) * a.H2 + u] * wa, red, nwv);
+        const float s = block_sum(live ? a.hout[(w * a.T + a.lo + t) * a.H2 + u] * wa : 0.f, red, nwv);
         if (u == 0) sc[t] = (s + a.b_att[0]) / temp;
     }
     __syncthreads();
@@ -366,10 +368,10 @@ __global__ __launch_bounds__(256) void pool_train_fwd_kernel(PoolArgs a, float* 
     float l = 0.f;
     for (int t = 0; t < nc; ++t) {
         const float aw = expf(sc[t] - mx) / den;
-        l = fmaf(aw, a.hout[(w * a.T + a.lo + t) * a.H2 + u], l);
+        if (live) l = fmaf(aw, a.hout[(w * a.T + a.lo + t) * a.H2 + u], l);
         if (u == 0) { attw[w * nc + t] = aw; scores[w * nc + t] = sc[t]; }
     }
-    latent[w * a.H2 + u] = l;
+    if (live) latent[w * a.H2 + u] = l;
     lat[u] = l;
     __syncthreads();
     if (u < a.C) {
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(256) void pool_train_bwd_kernel(PoolArgs a, const f
     __shared__ float dav[128];
     const int64_t w = blockIdx.x;
     const int u = threadIdx.x, nwv = blockDim.x >> 6, nc = a.hi - a.lo;
+    const bool live = u < a.H2;
     const float temp = softplus_temp(a.att_temp[0]);
     const float g = sigmoidf_(a.gate[0]);
     float dgate_c = 0.f;
@@ -404,34 +407,36 @@ __global__ __launch_bounds__(256) void pool_train_bwd_kernel(PoolArgs a, const f
         dgate_c = df * (lstm_logits[w * a.C + u] - a.lin_logits[w * a.C + u]) * g * (1.0f - g);
     }
     const float dgate = block_sum(dgate_c, red, nwv);            // (also orders the dl[] writes)
-    float dlat = dlat_cov ? dlat_cov[w * a.H2 + u] : 0.f;
-    for (int c = 0; c < a.C; ++c) dlat = fmaf(dl[c], a.w_lin2[c * a.H2 + u], dlat);
+    float dlat = dlat_cov && live ? dlat_cov[w * a.H2 + u] : 0.f;
+    if (live)
+        for (int c = 0; c < a.C; ++c) dlat = fmaf(dl[c], a.w_lin2[c * a.H2 + u], dlat);
     for (int t = 0; t < nc; ++t) {
-        const float s = block_sum(dlat * a.hout[(w * a.T + a.lo + t) * a.H2 + u], red, nwv);
+        const float s = block_sum(live ? dlat * a.hout[(w * a.T + a.lo + t) * a.H2 + u] : 0.f, red, nwv);
         if (u == 0) dav[t] = s;
     }
     __syncthreads();
     float dot = 0.f;
     for (int t = 0; t < nc; ++t) dot = fmaf(attw[w * nc + t], dav[t], dot);
     float dtemp = 0.f, dbatt = 0.f, dwatt = 0.f;
-    const float wa = a.w_att[u];
+    const float wa = live ? a.w_att[u] : 0.f;
+    const int uu = live ? u : 0;                                 // threads past 2h redo unit 0's arithmetic and store nothing
     for (int t = 0; t < a.T; ++t) {
         float dh = 0.f;
         if (t >= a.lo && t < a.hi) {
             const int tc = t - a.lo;
             const float aw = attw[w * nc + tc];
             const float ds = aw * (dav[tc] - dot);               // d loss / d score_t
-            const float hv = a.hout[(w * a.T + t) * a.H2 + u];
+            const float hv = a.hout[(w * a.T + t) * a.H2 + uu];
             dh = aw * dlat + ds / temp * wa;
             dwatt = fmaf(ds / temp, hv, dwatt);
             dbatt += ds / temp;
             dtemp -= ds * scores[w * nc + tc] / temp;
         }
-        dhout[(w * a.T + t) * a.H2 + u] = dh;
+        if (live) dhout[(w * a.T + t) * a.H2 + u] = dh;
     }
     const float raw = a.att_temp[0];
     float* p = part + w * (a.H2 + 12);
-    p[u] = dwatt;
+    if (live) p[u] = dwatt;
     if (u < 12) {
         float v = 0.f;
         if (u == 0) v = dbatt;
@@ -563,12 +568,12 @@ int launch_transpose_pad(const float* src, int64_t rows, int cols, int64_t ld, f
 static ExpandArgs make_expand_args(const TrainExpandParams& p) {
     ExpandArgs a{};
     a.proj = p.proj; a.tmat = p.tmat; a.lin_vec = p.lin_vec; a.b_bott = p.b_bott; a.ln_w = p.ln_w; a.ln_b = p.ln_b;
-    a.b_lin1 = p.b_lin1; a.T = p.T; a.Bn = p.Bn; a.NPROJ = p.NPROJ; a.C = p.C;
+    a.b_lin1 = p.b_lin1; a.T = p.T; a.Bn = p.Bn; a.NPROJ = p.NPROJ; a.C = p.C; a.NS = p.NS;
     for (int k = 0; k < 3; ++k) a.key[k] = p.key[k];
     a.thr = p.thr; a.scale = p.scale;
     return a;
 }
-static int expand_block(const TrainExpandParams& p) { return (int)round_up(3 * p.Bn, 64); }
+static int expand_block(const TrainExpandParams& p) { return (int)round_up(p.NS * p.Bn, 64); }
 
 // LDS bytes of the expand kernels: everything resident when it fits, otherwise the "big" form (U + row statistics only)
 static size_t expand_lds(int T, int Bn, int NPROJ, bool fwd, bool big) {
@@ -588,7 +593,7 @@ size_t train_expand_lds_bytes(int T, int Bn, int NPROJ) {
 int launch_train_expand_fwd(const TrainExpandParams& p, int64_t n_windows, float* Y, float* aug, float* lin_logits,
                             hipStream_t st) {
     const int block = expand_block(p);
-    if (block > 768 || p.C > 3 * p.Bn) return -1;
+    if (block > 768 || p.C > p.NS * p.Bn || (p.NS != 2 && p.NS != 3)) return -1;
     const bool big = expand_big(p.T, p.Bn, p.NPROJ);
     const size_t lds = expand_lds(p.T, p.Bn, p.NPROJ, true, big);
     if (lds > 160 * 1024) return -1;
@@ -607,7 +612,7 @@ int launch_train_expand_fwd(const TrainExpandParams& p, int64_t n_windows, float
 int launch_train_expand_bwd(const TrainExpandParams& p, int64_t n_windows, const float* Y, const float* daug, const float* dlin,
                             float* dproj, float* part, hipStream_t st) {
     const int block = expand_block(p);
-    if (block > 768) return -1;
+    if (block > 768 || (p.NS != 2 && p.NS != 3) || p.NPROJ - p.NS * p.Bn > block) return -1;
     const bool big = expand_big(p.T, p.Bn, p.NPROJ);
     const size_t lds = expand_lds(p.T, p.Bn, p.NPROJ, false, big);
     if (lds > 160 * 1024) return -1;
@@ -634,18 +639,24 @@ int launch_gelu_dropout(const float* Z, float* io, int64_t n, unsigned long long
 int launch_lstm_train_fwd(const float* gin, const float* w_hh, int h, int T, int64_t n_windows, float* act, float* cst,
                           float* hout, hipStream_t st) {
     const dim3 grid((unsigned)n_windows, 2);
-    if (h == 64) hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(256), 0, st, gin, w_hh, T, act, cst, hout);
-    else if (h == 128) hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(512), 0, st, gin, w_hh, T, act, cst, hout);
-    else return -1;
+    switch (h) {
+#define CBAS_CASE(H) case H: hipLaunchKernelGGL(lstm_train_fwd_kernel<H>, grid, dim3(4 * H), 0, st, gin, w_hh, T, act, cst, hout); break;
+        CBAS_CASE(16) CBAS_CASE(32) CBAS_CASE(48) CBAS_CASE(64) CBAS_CASE(80) CBAS_CASE(96) CBAS_CASE(112) CBAS_CASE(128)
+#undef CBAS_CASE
+        default: return -1;
+    }
     return CHECK_LAUNCH();
 }
 
 int launch_lstm_train_bwd(const float* dhout, const float* act, const float* cst, const float* hout, const float* w_hh, int h,
                           int T, int64_t n_windows, float* dgin, float* hprev, hipStream_t st) {
     const dim3 grid((unsigned)n_windows, 2);
-    if (h == 64) hipLaunchKernelGGL(lstm_train_bwd_kernel<64>, grid, dim3(256), 0, st, dhout, act, cst, hout, w_hh, T, dgin, hprev);
-    else if (h == 128) hipLaunchKernelGGL(lstm_train_bwd_kernel<128>, grid, dim3(512), 0, st, dhout, act, cst, hout, w_hh, T, dgin, hprev);
-    else return -1;
+    switch (h) {
+#define CBAS_CASE(H) case H: hipLaunchKernelGGL(lstm_train_bwd_kernel<H>, grid, dim3(4 * H), 0, st, dhout, act, cst, hout, w_hh, T, dgin, hprev); break;
+        CBAS_CASE(16) CBAS_CASE(32) CBAS_CASE(48) CBAS_CASE(64) CBAS_CASE(80) CBAS_CASE(96) CBAS_CASE(112) CBAS_CASE(128)
+#undef CBAS_CASE
+        default: return -1;
+    }
     return CHECK_LAUNCH();
 }
 
@@ -658,8 +669,8 @@ static PoolArgs make_pool_args(const TrainPoolParams& p) {
 
 int launch_pool_train_fwd(const TrainPoolParams& p, int64_t n_windows, float* attw, float* scores, float* latent,
                           float* lstm_logits, float* final_logits, hipStream_t st) {
-    if (p.H2 % 64 || p.H2 > 256 || p.C > 64 || p.hi - p.lo > 128 || p.hi <= p.lo) return -1;
-    hipLaunchKernelGGL(pool_train_fwd_kernel, dim3((unsigned)n_windows), dim3(p.H2), 0, st, make_pool_args(p), attw, scores,
+    if (p.H2 % 32 || p.H2 > 256 || p.C > 64 || p.hi - p.lo > 128 || p.hi <= p.lo) return -1;
+    hipLaunchKernelGGL(pool_train_fwd_kernel, dim3((unsigned)n_windows), dim3((unsigned)round_up(p.H2, 64)), 0, st, make_pool_args(p), attw, scores,
                        latent, lstm_logits, final_logits);
     return CHECK_LAUNCH();
 }
@@ -667,8 +678,8 @@ int launch_pool_train_fwd(const TrainPoolParams& p, int64_t n_windows, float* at
 int launch_pool_train_bwd(const TrainPoolParams& p, int64_t n_windows, const float* attw, const float* scores,
                           const float* lstm_logits, const float* dfinal, const float* dlat_cov, float* dhout,
                           float* dlstm_logits, float* dlin_logits, float* part, hipStream_t st) {
-    if (p.H2 % 64 || p.H2 > 256 || p.C > 64 || p.hi - p.lo > 128 || p.hi <= p.lo) return -1;
-    hipLaunchKernelGGL(pool_train_bwd_kernel, dim3((unsigned)n_windows), dim3(p.H2), 0, st, make_pool_args(p), attw, scores,
+    if (p.H2 % 32 || p.H2 > 256 || p.C > 64 || p.hi - p.lo > 128 || p.hi <= p.lo) return -1;
+    hipLaunchKernelGGL(pool_train_bwd_kernel, dim3((unsigned)n_windows), dim3((unsigned)round_up(p.H2, 64)), 0, st, make_pool_args(p), attw, scores,
                        lstm_logits, dfinal, dlat_cov, dhout, dlstm_logits, dlin_logits, part);
     return CHECK_LAUNCH();
 }

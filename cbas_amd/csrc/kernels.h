@@ -202,6 +202,7 @@ struct TrainExpandParams {
     const float* lin_vec;    // [T] mean over the centre window of the EMA rows
     const float *b_bott, *ln_w, *ln_b, *b_lin1;
     int T, Bn, NPROJ, C;
+    int NS;                      // bottleneck streams (3, or 2 without the acceleration stream)
     unsigned long long key[3];   // dropout stream keys of the three bottlenecks for this step
     unsigned thr;                // keep <=> hash24 >= thr
     float scale;                 // 1 / (1 - p)

@@ -28,9 +28,10 @@ from .weights import head_param_shapes
 
 def head_weight_names(cfg: HeadConfig) -> List[str]:
     names = ["gate", "attention_temp"]
-    for s in ("cls", "delta", "acc"):
+    streams = ("cls", "delta", "acc") if cfg.use_acceleration else ("cls", "delta")      # classifier_head.py:74-84
+    for s in streams:
         names += [f"{s}_bottleneck.0.weight", f"{s}_bottleneck.0.bias"]
-    for s in ("cls", "delta", "acc"):
+    for s in streams:
         names += [f"{s}_ln.weight", f"{s}_ln.bias"]
     names += ["lin0.0.weight", "lin0.0.bias", "lin1.weight", "lin1.bias"]
     for layer in range(cfg.lstm_layers):
@@ -61,9 +62,9 @@ class HeadTrainer:
                  weight_decay: float = 0.0, label_smoothing: float = 0.0, class_weights: Optional[Sequence[float]] = None,
                  max_batch: int = 512, seed: int = 0, dropout: bool = True):
         cfg.validate()
-        if not cfg.use_acceleration or cfg.lstm_hidden_size not in (64, 128):
-            raise NotImplementedError("on-device training is built for the 3-stream head with lstm_hidden_size 64 or 128 "
-                                      "(the configurations train_lstm_model / sweep_runner.py use); inference supports more")
+        if cfg.lstm_hidden_size % 16 or not 16 <= cfg.lstm_hidden_size <= 128:
+            raise NotImplementedError("on-device training is built for lstm_hidden_size = 16, 32, ... 128 (train_lstm_model's "
+                                      f"default is 64, sweep_runner.py uses 128); got {cfg.lstm_hidden_size}")
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -71,7 +72,7 @@ class HeadTrainer:
         self._lib = _lib.load()
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._cc = _lib.HeadConfigC(cfg.in_features, cfg.out_features, cfg.seq_len, cfg.bottleneck_dim, cfg.lin0_dim,
-                                    cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers, 1)
+                                    cfg.lstm_hidden_size, cfg.center_window_size, cfg.ema_alpha, cfg.lstm_layers, int(cfg.use_acceleration))
         tc = _lib.TrainConfigC(float(lr), float(weight_decay), float(label_smoothing), int(max_batch), int(seed) & (2 ** 64 - 1),
                                1 if dropout else 0)
         blob = pack_head_weights(cfg, weights)

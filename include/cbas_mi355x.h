@@ -324,7 +324,9 @@ typedef struct cbas_train_config {
     int32_t  dropout;          /* 1: Dropout(0.1) x3 + Dropout(0.15) as in train();  0: off */
 } cbas_train_config;
 
-/* weights_host: the same blob cbas_head_create takes.  class_weights_host: C floats or NULL. */
+/* weights_host: the same blob cbas_head_create takes.  class_weights_host: C floats or NULL.
+ * Configurations: lstm_hidden_size 16, 32, ... 128; 3 or 2 bottleneck streams (use_acceleration); 1-4 LSTM layers;
+ * seq_len 3..101; bottleneck_dim a multiple of 64; out_features <= 64. */
 int cbas_head_train_create(const cbas_head_config* cfg, const cbas_train_config* tcfg, const float* weights_host,
                            int64_t n_weights, const float* class_weights_host, int device_id,
                            cbas_head_trainer** out);

@@ -117,7 +117,10 @@ def forward_train(x: torch.Tensor, w: Dict[str, torch.Tensor], seq_len: int = 31
         y = _drop(y, None if masks is None else masks[name], P_BOTTLENECK)
         return F.layer_norm(y, (y.shape[-1],), w[f"{name}_ln.weight"], w[f"{name}_ln.bias"], 1e-5)
 
-    aug = torch.cat([bott(s, "cls"), bott(d, "delta"), bott(a, "acc")], dim=-1)
+    streams = [bott(s, "cls"), bott(d, "delta")]
+    if "acc_bottleneck.0.weight" in w:                                                    # use_acceleration (:74-84, :158-162)
+        streams.append(bott(a, "acc"))
+    aug = torch.cat(streams, dim=-1)
     xl = F.gelu(aug @ w["lin0.0.weight"].T + w["lin0.0.bias"])                             # :164
     xl = _drop(xl, None if masks is None else masks["lin0"], P_LIN0)
     xl = xl - xl.mean(dim=1, keepdim=True)                                                 # :166-167

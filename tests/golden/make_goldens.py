@@ -344,17 +344,23 @@ def g_head_train(out):
     _, classifier_head = import_reference()
     from oracle import head_train_oracle as HT
     torch.set_grad_enabled(True)                 # the rest of this script runs under no-grad
-    for tag, h, nl, B, wd, ls, use_cw in (("h64", 64, 1, 48, 0.0, 0.0, False), ("h64_l2", 64, 2, 32, 1e-2, 0.1, True),
-                                          ("h128", 128, 1, 32, 0.0, 0.05, True)):
-        hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl)
+    for tag, h, nl, B, wd, ls, use_cw, acc in (("h64", 64, 1, 48, 0.0, 0.0, False, True), ("h64_l2", 64, 2, 32, 1e-2, 0.1, True, True),
+                                               ("h128", 128, 1, 32, 0.0, 0.05, True, True),
+                                               # what the UI's free "LSTM hidden size" field and a 2-stream checkpoint lead to
+                                               ("h32", 32, 1, 24, 0.0, 0.0, False, True), ("h96_noacc", 96, 1, 24, 1e-3, 0.05, True, False),
+                                               ("h48_noacc_l2", 48, 2, 20, 0.0, 0.0, False, False)):
+        if getattr(g_head_train, "only", None) and tag not in g_head_train.only:
+            continue
+        hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl, use_acceleration=acc)
         hw = W.synth_head_weights(hcfg, HEAD_SEED)
         m = classifier_head.ClassifierLSTMDeltas(in_features=768, out_features=9, seq_len=31, lstm_hidden_size=h,
-                                                 lstm_layers=nl)
+                                                 lstm_layers=nl, use_acceleration=acc)
         m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in hw.items()}, strict=True)
         bank = {"masks": None}
         m.cls_bottleneck[2] = _MaskDropout(0.1, "cls", bank)
         m.delta_bottleneck[2] = _MaskDropout(0.1, "delta", bank)
-        m.acc_bottleneck[2] = _MaskDropout(0.1, "acc", bank)
+        if acc:
+            m.acc_bottleneck[2] = _MaskDropout(0.1, "acc", bank)
         m.lin0[2] = _MaskDropout(0.15, "lin0", bank)
         m.train()
         lr, seed, n_steps = 1e-3, 77, 3
@@ -535,7 +541,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--out", default=HERE)
+    ap.add_argument("--train-tags", default=None, help="head_train: only these fixtures (e.g. h32,h96_noacc)")
     a = ap.parse_args()
+    g_head_train.only = a.train_tags.split(",") if a.train_tags else None
     for k, fn in ALL.items():
         if a.only and k not in a.only.split(","):
             continue

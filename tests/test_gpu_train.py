@@ -12,14 +12,16 @@ from cbas_amd import config as C, synth, weights as W
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = {"h64": (64, 1), "h64_l2": (64, 2), "h128": (128, 1)}
+CASES = {"h64": (64, 1, True), "h64_l2": (64, 2, True), "h128": (128, 1, True),
+         # other hidden sizes (the UI's "LSTM hidden size" is free: app.py:321) and the 2-stream head (classifier_head.py:74-84)
+         "h32": (32, 1, True), "h96_noacc": (96, 1, False), "h48_noacc_l2": (48, 2, False)}
 STRIDE = 13
 
 
 def golden(tag):
-    h, nl = CASES[tag]
+    h, nl, acc = CASES[tag]
     g = np.load(os.path.join(GOLD, f"head_train_{tag}.npz"))
-    hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl)
+    hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl, use_acceleration=acc)
     hw = W.synth_head_weights(hcfg, 4321)
     x, y = synth.train_windows(5, int(g["B"]), 768, 9, 31)
     cw = g["class_weights"] if "class_weights" in g.files else None
@@ -182,14 +184,16 @@ def test_train_lstm_model_shim_runs_the_reference_loop():
     model.close()
 
 
-@pytest.mark.parametrize("I,Cn,T,h,nl,B", [(384, 4, 15, 64, 1, 20), (768, 12, 41, 128, 2, 9),
-                                           (768, 9, 63, 64, 1, 10), (768, 5, 95, 128, 1, 6)])     # sweep_runner.py:110 lengths
-def test_other_shapes_against_oracle(I, Cn, T, h, nl, B):
+@pytest.mark.parametrize("I,Cn,T,h,nl,B,acc", [(384, 4, 15, 64, 1, 20, True), (768, 12, 41, 128, 2, 9, True),
+                                               (768, 9, 63, 64, 1, 10, True), (768, 5, 95, 128, 1, 6, True),     # sweep_runner.py:110 lengths
+                                               (768, 9, 31, 16, 1, 12, True), (768, 3, 31, 80, 2, 7, False),
+                                               (384, 9, 63, 112, 1, 5, False)])
+def test_other_shapes_against_oracle(I, Cn, T, h, nl, B, acc):
     """ViT-S width / short windows / 12 classes / long windows with a stacked h=128 LSTM / the sweep's 63- and 95-frame
     windows (the expand kernels then keep only U in LDS and read the projected rows from global memory): gradients vs
     float64 autograd."""
     from oracle import head_train_oracle as HT
-    hcfg = C.HeadConfig(in_features=I, out_features=Cn, seq_len=T, lstm_hidden_size=h, lstm_layers=nl)
+    hcfg = C.HeadConfig(in_features=I, out_features=Cn, seq_len=T, lstm_hidden_size=h, lstm_layers=nl, use_acceleration=acc)
     hw = W.synth_head_weights(hcfg, 99)
     x, y = synth.train_windows(17, B, I, Cn, T)
     tr = make_trainer(hcfg, hw, lr=1e-3, weight_decay=1e-2, dropout=True, seed=5)

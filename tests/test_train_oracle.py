@@ -11,7 +11,9 @@ from cbas_amd import config as C, synth, weights as W
 from oracle import head_train_oracle as HT
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = {"h64": (64, 1), "h64_l2": (64, 2), "h128": (128, 1)}
+CASES = {"h64": (64, 1, True), "h64_l2": (64, 2, True), "h128": (128, 1, True),
+         # other hidden sizes (the UI's "LSTM hidden size" is free: app.py:321) and the 2-stream head (classifier_head.py:74-84)
+         "h32": (32, 1, True), "h96_noacc": (96, 1, False), "h48_noacc_l2": (48, 2, False)}
 STRIDE = 13
 
 
@@ -28,9 +30,9 @@ def like(a, is_sample):
 
 
 def problem(tag):
-    h, nl = CASES[tag]
+    h, nl, acc = CASES[tag]
     g = np.load(os.path.join(GOLD, f"head_train_{tag}.npz"))
-    hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl)
+    hcfg = C.HeadConfig(in_features=768, out_features=9, lstm_hidden_size=h, lstm_layers=nl, use_acceleration=acc)
     hw = W.synth_head_weights(hcfg, 4321)
     x, y = synth.train_windows(5, int(g["B"]), 768, 9, 31)
     cw = g["class_weights"] if "class_weights" in g.files else None
