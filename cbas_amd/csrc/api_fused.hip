@@ -171,8 +171,10 @@ extern "C" int cbas_fused_push_u8(cbas_fused* f, const uint8_t* frames_dev, int 
     return push(f, frames_dev, false, n, height, width, frame_stride, row_stride, pixel_stride, after_stream);
 }
 
-extern "C" int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev,
-                                 const float** probs_dev, int64_t* n_frames, void* stream) {
+namespace {
+// mode 0: the host waits; 1: `stream` waits; 2: nobody waits (cbas_fused_wait does, later)
+int finish_impl(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev, const float** probs_dev,
+                int64_t* n_frames, int mode, hipStream_t stream) {
     if (!f) return cbas_fail(CBAS_EINVAL, "null session");
     HIP_TRY(hipSetDevice(f->device));
     int rc = drain(f);
@@ -190,11 +192,28 @@ extern "C" int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* p
     if (n_frames) *n_frames = f->encoded;
     HIP_TRY(hipEventRecord(f->clip_done, f->st));
     f->clip_pending = true;
-    if (stream) {                                                       // `stream` waits for the results, the host does not
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, f->clip_done, 0));
-    } else {
+    if (mode == 1) {                                                    // `stream` waits for the results, the host does not
+        HIP_TRY(hipStreamWaitEvent(stream, f->clip_done, 0));
+    } else if (mode == 0) {
         HIP_TRY(hipEventSynchronize(f->clip_done));                     // results are complete at return
         f->clip_pending = false;
     }
+    return CBAS_OK;
+}
+}  // namespace
+
+extern "C" int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev,
+                                 const float** probs_dev, int64_t* n_frames, void* stream) {
+    return finish_impl(f, cls_f16_host, probs_host, cls_f16_dev, probs_dev, n_frames, stream ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int cbas_fused_finish_async(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, int64_t* n_frames) {
+    return finish_impl(f, cls_f16_host, probs_host, nullptr, nullptr, n_frames, 2, nullptr);
+}
+
+extern "C" int cbas_fused_wait(cbas_fused* f) {
+    if (!f) return cbas_fail(CBAS_EINVAL, "null session");
+    HIP_TRY(hipSetDevice(f->device));
+    if (f->clip_pending) { HIP_TRY(hipEventSynchronize(f->clip_done)); f->clip_pending = false; }
     return CBAS_OK;
 }

@@ -135,6 +135,11 @@ class _ClipQueue:
             i = int(self._store.add(self._key, 1)) - 1
         return i if i < self.n else None
 
+    def remaining(self) -> int:
+        """Clips nobody has taken yet (a snapshot: other ranks keep taking them)."""
+        taken = self._local if self._store is None else int(self._store.add(self._key, 0))
+        return max(0, self.n - taken)
+
 
 class _OutputWriter:
     """Rank 0's file writers, off the encode loop's critical path: ``_cls.h5`` files on ONE thread (libhdf5 is not
@@ -357,14 +362,32 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     if pipelined and runner.native and len(runner._sessions) < 2:
         runner._sessions.append(None)
     prev = None                                            # (clip, pending result) of the clip before the current one
+    # Look-ahead: while clip i is pushed, a helper thread opens clip i+1 and decodes its first pieces into page-locked buffers,
+    # so the GPU does not idle through "open the file, walk its index, decode 128 frames" (8-9 ms in a rocprofv3 timeline)
+    # between clips.  The next clip is taken from the queue one clip early for that - only while at least one untaken clip
+    # per rank is left, so the queue's tail stays as dynamic as it was.
+    ahead = None                                           # (clip, Future of a prepared clip) taken from the queue early
+    pool = None
+    if pipelined and runner.native:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cbas-open-ahead")
     try:
         while True:
-            clip = queue_.next()
+            if ahead is not None:
+                clip, fut = ahead
+                ahead = None
+                prepared = fut.result()
+            else:
+                clip, prepared = queue_.next(), None
             if clip is None:
                 break
+            if pool is not None and queue_.remaining() >= world:
+                nxt = queue_.next()
+                if nxt is not None:
+                    ahead = (nxt, pool.submit(runner.prepare, paths[nxt]))
             try:
                 if pipelined:
-                    cur = runner.submit(paths[clip], None, progress_callback)
+                    cur = runner.submit(paths[clip], None, progress_callback, prepared=prepared)
                 else:
                     cur = P._PendingClip(runner.run(paths[clip], None, progress_callback, device_out=True), None)
             except Exception as e:  # noqa: BLE001 - the queue survives a bad file (workthreads.py:334-336)
@@ -401,6 +424,13 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 _wait_done(w)
         finished = True
     finally:
+        if ahead is not None:                              # an error is on its way up with a clip opened ahead
+            try:
+                ahead[1].result().close()
+            except BaseException:  # noqa: BLE001
+                pass
+        if pool is not None:
+            pool.shutdown(wait=True)
         if rank == 0:
             if not finished:
                 stop.set()                                 # an error is on its way up: do not wait for tickets that will not come

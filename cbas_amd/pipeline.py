@@ -680,22 +680,54 @@ class ClipRunner:
         ent[0].reset()
         return ent
 
-    def submit(self, path: str, reader=None, progress_callback=None) -> "_PendingClip":
+    def prepare(self, path: str) -> "_PreparedClip":
+        """Open ``path`` and start decoding its first pieces into page-locked buffers NOW, for a ``submit`` that comes
+        later: with this called for clip i+1 before clip i is pushed, the next clip's frames are already waiting when
+        the current one ends (opening a file and decoding its first piece otherwise leave the GPU idle for ~8 ms between
+        clips).  Reader errors surface from ``submit``."""
+        if not self.native:
+            return _PreparedClip(path, None, 0, None, None)
+        try:
+            reader = open_video(path)
+        except BaseException as e:  # noqa: BLE001 - reported when the clip's turn comes
+            return _PreparedClip(path, None, 0, None, e)
+        try:
+            n = len(reader)
+            chunks = _chunks(reader, n, pinned=True, piece=PIECE) if n > 0 else None
+        except BaseException as e:  # noqa: BLE001
+            if hasattr(reader, "close"):
+                reader.close()
+            return _PreparedClip(path, None, 0, None, e)
+        return _PreparedClip(path, reader, n, chunks, None)
+
+    def submit(self, path: str, reader=None, progress_callback=None, prepared: "Optional[_PreparedClip]" = None) -> "_PendingClip":
         """``run`` split in two for back-to-back clips: every frame of the video is pushed and the tail (last batches,
         tail classification, copy-out into page-locked memory) is QUEUED, not waited for; ``.result()`` of the returned
         object waits and gives the ClipResult (``None`` for a video without frames).  Call it after the NEXT clip has been
-        submitted (sessions alternate: needs ``sessions >= 2``) and the GPU never idles between clips."""
-        if not self.native or len(self._sessions) < 2:
-            return _PendingClip(self.run(path, reader, progress_callback), None)
-        own_reader = reader is None
-        reader = reader if reader is not None else open_video(path)
+        submitted (sessions alternate: needs ``sessions >= 2``) and the GPU never idles between clips.  ``prepared``: what
+        ``prepare(path)`` returned (reader open, first pieces decoded)."""
+        if prepared is not None and prepared.error is not None:
+            raise prepared.error
+        if prepared is not None and prepared.reader is not None:
+            reader, chunks, own_reader = prepared.reader, prepared.chunks, True
+            prepared.reader = prepared.chunks = None
+        else:
+            chunks = None
+            if not self.native or len(self._sessions) < 2:
+                return _PendingClip(self.run(path, reader, progress_callback), None)
+            own_reader = reader is None
+            reader = reader if reader is not None else open_video(path)
         try:
             video_len = len(reader)
             if video_len == 0:
                 print(f"Warning: Video {path} contains no frames. Skipping.")
                 return _PendingClip(None, None)
-            return self._run_native(reader, video_len, progress_callback, False, wait=False)
+            if len(self._sessions) < 2:
+                return _PendingClip(self._run_native(reader, video_len, progress_callback, False, chunks=chunks), None)
+            return self._run_native(reader, video_len, progress_callback, False, wait=False, chunks=chunks)
         finally:
+            if chunks is not None:
+                chunks.close()                     # (already closed on the normal path; stops the decoder on an error)
             if own_reader and hasattr(reader, "close"):
                 reader.close()
 
@@ -722,12 +754,13 @@ class ClipRunner:
             if own_reader and hasattr(reader, "close"):
                 reader.close()
 
-    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool, wait: bool = True):
+    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool, wait: bool = True, chunks=None):
         enc = self.encoder
         ent = None
         sub = 0                                      # sub-batches submitted so far
         held: deque = deque()                        # (chunk frames, sub-batch count after which its copies are done)
-        chunks = _chunks(reader, video_len, pinned=True, piece=PIECE)
+        if chunks is None:
+            chunks = _chunks(reader, video_len, pinned=True, piece=PIECE)
         with contextlib.closing(chunks):
             for i, _end_index, frames in chunks:
                 _progress(progress_callback, i, video_len)
@@ -760,6 +793,22 @@ class ClipRunner:
             while held:
                 chunks.release(held.popleft()[0])
         return res
+
+
+class _PreparedClip:
+    """What ``ClipRunner.prepare`` returns: an open reader whose first pieces are being decoded (or the error opening it)."""
+
+    def __init__(self, path, reader, n, chunks, error):
+        self.path, self.reader, self.frames, self.chunks, self.error = path, reader, n, chunks, error
+
+    def close(self) -> None:
+        """Drop a prepared clip that will not be submitted."""
+        if self.chunks is not None:
+            self.chunks.close()
+            self.chunks = None
+        if self.reader is not None and hasattr(self.reader, "close"):
+            self.reader.close()
+        self.reader = None
 
 
 class _PendingClip:

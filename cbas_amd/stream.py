@@ -29,6 +29,16 @@ def _layout(frames, channel: int):
     return n, H, W, (H * W, W, 1), 0
 
 
+class _ClipWait:
+    """``synchronize()`` = the clip a session finished asynchronously is complete in host memory."""
+
+    def __init__(self, session: "ClipStream"):
+        self._s = session
+
+    def synchronize(self) -> None:
+        self._s.wait()
+
+
 class ClipStream:
     """``head=None`` gives an encode-only session: the chunk loop of ``encode_file`` with the rows kept in HBM."""
 
@@ -116,19 +126,22 @@ class ClipStream:
 
     def finish_host_async(self):
         """``finish_host`` without blocking: the tail classification and the copy-out are queued, and the call returns
-        (cls_f16, probs, event) - page-locked numpy arrays that are complete once ``event.synchronize()`` has returned.
-        The next clip can be pushed through ANOTHER session meanwhile (this session's buffers are in use until then)."""
+        (cls_f16, probs, waiter) - page-locked numpy arrays that are complete once ``waiter.synchronize()`` has returned
+        (``cbas_fused_finish_async`` / ``cbas_fused_wait``).  The next clip can be pushed through ANOTHER session meanwhile
+        (this session's buffers are in use until then)."""
         D, Cn = self.enc.config.hidden_size, (self.head.out_features if self.head is not None else 0)
         o16 = torch.empty((self.encoded, D), dtype=torch.float16, pin_memory=True).numpy()
         opr = torch.empty((self.encoded, Cn), dtype=torch.float32, pin_memory=True).numpy() if Cn else np.empty((self.encoded, 0), np.float32)
         n = C.c_int64(0)
-        ts = torch.cuda.current_stream(self.enc.device)
-        _lib.check(self._lib.cbas_fused_finish(self._h, o16.ctypes.data, opr.ctypes.data if Cn else None, None, None,
-                                               C.byref(n), ts.cuda_stream), "cbas_fused_finish")
+        _lib.check(self._lib.cbas_fused_finish_async(self._h, o16.ctypes.data, opr.ctypes.data if Cn else None, C.byref(n)),
+                   "cbas_fused_finish_async")
         assert int(n.value) == self.encoded
-        ev = torch.cuda.Event()
-        ev.record(ts)
-        return o16, opr, ev
+        return o16, opr, _ClipWait(self)
+
+    def wait(self) -> None:
+        """Block until the clip queued by ``finish_host_async`` is complete."""
+        if self._h:
+            _lib.check(self._lib.cbas_fused_wait(self._h), "cbas_fused_wait")
 
     def finish_host(self) -> Tuple[np.ndarray, np.ndarray]:
         """Classify the tail and copy the clip out: (cls_f16 (N,D) float16, probs (N,C) float32) numpy arrays."""

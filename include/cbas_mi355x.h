@@ -304,6 +304,13 @@ int cbas_fused_push_u8(cbas_fused* f, const uint8_t* frames_dev, int n, int heig
  * that point: record an event there and wait for it); the next clip may be pushed through another session meanwhile. */
 int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const uint16_t** cls_f16_dev,
                       const float** probs_dev, int64_t* n_frames, void* stream);
+/* cbas_fused_finish for back-to-back clips: everything is QUEUED (last batches, tail classification, the copies into the
+ * page-locked host buffers) and the call returns at once; cbas_fused_wait(f) blocks until that clip's results are complete
+ * (a no-op when nothing is pending).  Push the next clip through ANOTHER session in between and the device never idles
+ * at a clip boundary.  (Ordering another stream after the clip - the `stream` form above - is not used for this: handed the
+ * legacy NULL stream, hipStreamWaitEvent blocks the HOST until the event has completed, 15 ms at the end of every clip.) */
+int cbas_fused_finish_async(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, int64_t* n_frames);
+int cbas_fused_wait(cbas_fused* f);
 
 /* ---- head training -------------------------------------------------------------------------
  * Replaces the optimisation step inside train_lstm_model (backend/cbas.py:1326-1348):

@@ -20,7 +20,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(fmt: str, n: int) -> None:
+def run(fmt: str, n: int, clips: int = 1) -> None:
     import tempfile
     import numpy as np
     import torch
@@ -48,6 +48,28 @@ def run(fmt: str, n: int) -> None:
         np.save(path, fr)
     del fr, g, g8, low
     names = [f"b{i}" for i in range(9)]
+    if clips > 1:                                    # the multi-clip product path: N copies of the clip through dist.encode_files
+        from cbas_amd import dist as cdist
+        paths = []
+        for k in range(clips):
+            d = os.path.join(root, f"c{k}")
+            os.makedirs(d)
+            q = os.path.join(d, "clip." + fmt)
+            os.symlink(path, q)
+            paths.append(q)
+        for k in range(2):
+            torch.cuda.synchronize()
+            time.sleep(0.4)
+            t0 = time.perf_counter()
+            recs = cdist.encode_files(paths, enc, head=head, dataset_name="tl", behaviors=names)
+            dt = time.perf_counter() - t0
+            assert all(r["status"] == "ok" for r in recs)
+            print(f"pass {k}: {clips} clips, {clips * n / dt:.0f} frames/s ({dt * 1e3:.1f} ms)", flush=True)
+        head.close()
+        enc.close()
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
+        return
     for k in range(2):
         torch.cuda.synchronize()
         time.sleep(0.4)
@@ -112,7 +134,9 @@ def report(d: str, out_json=None) -> None:
     d2h = _union([(s, e) for s, e, dr in cop if "DEVICE_TO_HOST" in dr.upper()])
     both = _intersect(ku, h2d)
     gemm = _union([(s, e) for s, e, n in kern if "gemm_f16_8ph" in n])
+    gaps = sorted(((ku[i + 1][0] - ku[i][1]) / 1e6 for i in range(len(ku) - 1)), reverse=True)
     res = {
+        "largest_kernel_idle_gaps_ms": [round(g, 3) for g in gaps[:8]], "idle_total_ms": round(sum(gaps), 3),
         "span_ms": span / 1e6, "kernels": len(kern), "copies": len(cop),
         "kernel_busy": _length(ku) / span, "gemm_busy": _length(gemm) / span,
         "h2d_busy": _length(h2d) / span, "d2h_busy": _length(d2h) / span,
@@ -128,6 +152,7 @@ def report(d: str, out_json=None) -> None:
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(sys.argv[2] if len(sys.argv) > 2 else "avi", int(sys.argv[3]) if len(sys.argv) > 3 else 8192)
+        run(sys.argv[2] if len(sys.argv) > 2 else "avi", int(sys.argv[3]) if len(sys.argv) > 3 else 8192,
+            int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     else:
         report(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
