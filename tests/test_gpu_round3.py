@@ -211,6 +211,46 @@ def test_encode_files_world1_never_writes_on_the_encode_thread(tmp_path, monkeyp
         enc.close()
 
 
+def test_encode_files_survives_bad_clips_opened_ahead(tmp_path):
+    """Clips are opened one ahead on a helper thread (ClipRunner.prepare): a missing file, a file that is not a video and a
+    Motion-JPEG clip with a damaged frame fail at THEIR turn - as EncodeThread logs and skips (workthreads.py:334-336) - and
+    the clips around them come out byte-identical to the same clips run alone."""
+    from cbas_amd import dist as cdist, framesource as F, pipeline as P
+    cfg, enc, head = _tiny()
+    names = list("abcde")
+    try:
+        good = []
+        for i, n in enumerate((300, 130, 45)):
+            d = tmp_path / f"g{i}"
+            d.mkdir()
+            p = str(d / ("clip.avi" if i == 1 else "clip.npy"))
+            fr = synth.cage_frames(80 + i, n, 64, 64)
+            F.write_mjpeg_avi(p, fr, quality=90) if p.endswith(".avi") else np.save(p, fr)
+            good.append(p)
+        alone = [tuple(_sha(x) for x in P.encode_infer_file(enc, head, p, "ds", names)) for p in good]
+        junk = str(tmp_path / "junk.avi")
+        open(junk, "wb").write(b"RIFF" + bytes(range(200)))
+        broken = str(tmp_path / "broken.avi")
+        raw = bytearray(open(good[1], "rb").read())
+        src = F.MJPEGAviSource(good[1])
+        off, size = src._frames[100]                                    # a frame past the first pieces: its header destroyed
+        src.close()
+        raw[off:off + 64] = bytes(64)
+        open(broken, "wb").write(bytes(raw))
+        paths = [good[0], str(tmp_path / "missing.npy"), good[1], junk, broken, good[2]]
+        recs = cdist.encode_files(paths, enc, head=head, dataset_name="ds", behaviors=names)
+        assert [r["status"] for r in recs] == ["ok", "failed", "ok", "failed", "failed", "ok"], [r["status"] for r in recs]
+        for r, want in zip([recs[0], recs[2], recs[5]], alone):
+            assert (_sha(r["cls_file"]), _sha(r["csv_file"])) == want
+        assert not os.path.exists(str(tmp_path / "broken_cls.h5")) and not os.path.exists(str(tmp_path / "broken_cls.h5.tmp"))
+        # and the encoder is still usable afterwards
+        again = tuple(_sha(x) for x in P.encode_infer_file(enc, head, good[0], "ds", names))
+        assert again == alone[0]
+    finally:
+        head.close()
+        enc.close()
+
+
 def test_encode_file_on_a_compressed_video_equals_its_decoded_frames(tmp_path):
     """Motion-JPEG AVI (real decoder work on the decode-ahead thread, frames landing in the page-locked ring) against the same
     decoded frames stored as .npy: identical `_cls.h5` rows and identical probabilities."""
