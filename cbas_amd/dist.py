@@ -19,6 +19,7 @@ from __future__ import annotations
 import os
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -543,3 +544,94 @@ def classify_sharded(head, local_cls16: torch.Tensor, temperature: float = 1.0) 
     if n_local:
         head.infer_range_into(buf, buf.shape[0], left.shape[0], n_local, probs, temperature)
     return probs[left.shape[0]:left.shape[0] + n_local]
+
+
+class _FrameRange:
+    """Frames [start, stop) of a reader, as a reader (``len``, ``get_batch``, ``read_into`` / ``frame_shape`` when the
+    underlying reader has them)."""
+
+    def __init__(self, reader, start: int, stop: int):
+        self._r, self._a, self._b = reader, int(start), int(stop)
+        if hasattr(reader, "frame_shape") and hasattr(reader, "read_into"):
+            self.frame_shape = reader.frame_shape
+            self.read_into = lambda i, j, out: reader.read_into(self._a + i, self._a + j, out)
+
+    def __len__(self):
+        return self._b - self._a
+
+    def get_batch(self, indices):
+        idx = indices if isinstance(indices, range) else list(indices)
+        if isinstance(idx, range) and idx.step == 1:
+            return self._r.get_batch(range(self._a + idx.start, self._a + idx.stop))
+        return self._r.get_batch([self._a + int(i) for i in idx])
+
+
+def encode_infer_file_sharded(path: str, encoder, head=None, dataset_name: Optional[str] = None,
+                              behaviors: Optional[Sequence[str]] = None, temperature: float = 1.0,
+                              progress_callback=None) -> Tuple[Optional[str], Optional[str]]:
+    """ONE video on all ranks (last sentence): rank r decodes and encodes the contiguous frame range
+    ``shard_frames(n, world, r)``, neighbouring ranks exchange the ``seq_len // 2`` CLS rows on either side of each cut
+    (``exchange_halo`` - the one real exchange step of the path, 23 KB per cut), every rank classifies its own frames, and
+    the rows / probabilities are gathered to rank 0 (``gather_rows``), which writes ``<video>_cls.h5`` and, with a head,
+    ``<video>_<dataset>_outputs.csv`` - byte for byte the files ``encode_file`` + ``infer_file`` write on one GPU (frames
+    are encoded independently; a window that straddles a cut sees the same rows).  Use it when there are fewer videos than
+    GPUs (one 30-minute clip at 10 fps = 18 000 frames: 2 250 per GPU at 8).  Every rank must call it; returns the two
+    paths on rank 0 (``None`` for the CSV without a head), (None, None) elsewhere and for a video without frames.
+    The reader must allow random access (decord, ``.npy``, Motion-JPEG AVI do; a sequential decoder pipe does not)."""
+    from . import pipeline as P
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if head is not None and (dataset_name is None or behaviors is None):
+        raise ValueError("classification needs dataset_name and behaviors (infer_file's arguments)")
+    D = encoder.config.hidden_size
+    reader = P.open_video(path)
+    try:
+        if getattr(reader, "decodes_ahead", False) and world > 1:
+            raise RuntimeError(f"{path}: its frame source reads sequentially; a clip can only be split over ranks with a "
+                               "random-access reader")
+        n = len(reader)
+        if n == 0:
+            if rank == 0:
+                print(f"Warning: Video {path} contains no frames. Skipping.")
+            return None, None
+        a, b = shard_frames(n, world, rank)
+        runner = P.ClipRunner(encoder, None)
+        try:
+            rows = None
+            if b > a:
+                res = runner.run(path, _FrameRange(reader, a, b), progress_callback if rank == 0 else None, device_out=True)
+                rows = res.rows if isinstance(res.rows, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(res.rows))
+            if rows is None:
+                rows = torch.empty((0, D), dtype=torch.float16, device=encoder.device if _on_gpu(encoder) else "cpu")
+            probs = None
+            if head is not None:
+                if hasattr(head, "to"):
+                    head.to(rows.device)
+                probs = classify_sharded(head, rows, temperature).contiguous()
+            g_rows = gather_rows([rows.contiguous()], dst=0)
+            g_probs = gather_rows([probs], dst=0) if probs is not None else None
+            if rows.is_cuda:
+                torch.cuda.synchronize(rows.device)        # the transfers read the session's buffers: done before it closes
+            if rank != 0:
+                return None, None
+            all_rows = torch.cat([t for per in g_rows for t in per]).cpu().numpy()
+            assert all_rows.shape == (n, D), (all_rows.shape, n)
+            cls_path = P.write_cls_file(path, all_rows, P.file_attrs(encoder))
+            print(f"Successfully encoded {os.path.basename(path)} to {os.path.basename(cls_path)}")
+            csv_path = None
+            if g_probs is not None:
+                all_probs = torch.cat([t for per in g_probs for t in per]).cpu().numpy()
+                csv_path = cls_path.replace("_cls.h5", f"_{dataset_name}_outputs.csv")
+                P.write_probs_csv(csv_path, all_probs, list(behaviors))
+            return cls_path, csv_path
+        finally:
+            runner.close()
+    finally:
+        if hasattr(reader, "close"):
+            reader.close()
+
+
+def _on_gpu(encoder) -> bool:
+    dev = getattr(encoder, "device", None)
+    return dev is not None and getattr(dev, "type", "cpu") == "cuda"
+

@@ -50,6 +50,9 @@ def main(argv=None) -> int:
     ap.add_argument("--encoder", required=True, help="encoder_model_identifier: checkpoint directory or cached HF id")
     ap.add_argument("--model-bundle", default=None, help="directory with model.pth + config.yaml + model_meta.json")
     ap.add_argument("--dataset-name", default=None, help="<video>_<dataset-name>_outputs.csv (default: the bundle's name)")
+    ap.add_argument("--split-clips", choices=("auto", "always", "never"), default="auto",
+                    help="split EACH video's frames over all GPUs (halo exchange at the cuts) instead of giving each GPU "
+                         "whole videos; auto: when there are fewer videos than GPUs")
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--max-frame", type=int, nargs=2, default=(256, 256))
     ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2),
@@ -92,12 +95,27 @@ def main(argv=None) -> int:
     hp = (meta or {}).get("hyperparameters", {})
     name = args.dataset_name or os.path.basename(os.path.normpath(args.model_bundle or "")) or None
     temperature = float((meta or {}).get("calibration", {}).get("temperature", 1.0))        # workthreads.py:484
-    recs = cdist.encode_files(videos, enc, head=head, dataset_name=name, behaviors=hp.get("behaviors"),
-                              temperature=temperature)
-    cdist.barrier()
-    if rank == 0:
-        ok = sum(r["status"] == "ok" for r in recs)
-        print(f"{ok} of {len(recs)} videos encoded on {world} GPU(s); {sum(r['frames'] for r in recs)} frames")
+    split = world > 1 and (args.split_clips == "always" or (args.split_clips == "auto" and len(videos) < world))
+    if split:
+        # fewer videos than GPUs: every GPU takes a frame range of each video (last sentence)
+        ok = 0
+        for v in videos:
+            try:
+                h5, _csv = cdist.encode_infer_file_sharded(v, enc, head=head, dataset_name=name, behaviors=hp.get("behaviors"),
+                                                           temperature=temperature)
+                ok += int(h5 is not None)
+            except Exception as e:  # noqa: BLE001 - EncodeThread logs and goes on (workthreads.py:334-336)
+                print(f"ERROR during encoding for {v} on rank {rank}: {e}")
+            cdist.barrier()
+        if rank == 0:
+            print(f"{ok} of {len(videos)} videos encoded, each split over {world} GPU(s)")
+    else:
+        recs = cdist.encode_files(videos, enc, head=head, dataset_name=name, behaviors=hp.get("behaviors"),
+                                  temperature=temperature)
+        cdist.barrier()
+        if rank == 0:
+            ok = sum(r["status"] == "ok" for r in recs)
+            print(f"{ok} of {len(recs)} videos encoded on {world} GPU(s); {sum(r['frames'] for r in recs)} frames")
     enc.close()
     return 0
 

@@ -241,3 +241,80 @@ def test_clips_come_from_a_shared_queue_not_round_robin(tmp_path):
     print(f"world 3: long clip on rank {long_rank}, clips per rank {taken}, {wall:.2f} s (round-robin: 1.8 s)")
     assert taken[long_rank] <= 2 and sum(taken) == 7
     assert wall < 1.6
+
+
+# ---- one long clip split over the ranks (last sentence) ---------------------------------------------
+class FrameExactEncoder(StubEncoder):
+    """The stand-in with arithmetic that cannot depend on how frames are batched (as the real encoder's does not): every
+    frame's feature is computed on its own, elementwise, in float64."""
+
+    def submit_host(self, slot, frames, channel=1):
+        assert slot not in self._slots
+        rows = []
+        for f in frames:
+            g = f[:, :, channel].astype(np.float64).ravel()
+            s = 1.0 + (g.sum() / g.size + 2.0 * g[0] + 3.0 * g[-1] + 5.0 * g[g.size // 2]) / 255.0
+            rows.append(np.cos(np.arange(D, dtype=np.float64) * s))
+        self._slots[slot] = np.asarray(rows, np.float64).reshape(len(frames), D).astype(np.float16)
+        self._slot_n[slot] = frames.shape[0]
+
+
+def _sharded_worker(rank, world, port, td, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    cdist.init_from_env("gloo")
+    P.set_project_stamp("facebook/dinov3-vitb16-pretrain-lvd1689m")
+    out = []
+    for name in sorted(f for f in os.listdir(td) if f.endswith(".npy")):
+        out.append(cdist.encode_infer_file_sharded(os.path.join(td, name), FrameExactEncoder(), head=StubHead(), dataset_name="gold",
+                                                   behaviors=NAMES, temperature=0.9))
+    enc_only = cdist.encode_infer_file_sharded(os.path.join(td, "only", "clipA.npy"), FrameExactEncoder())
+    if rank == 0:
+        q.put((out, enc_only))
+    else:
+        assert all(o == (None, None) for o in out) and enc_only == (None, None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_clip_split_over_ranks_writes_the_single_process_files(tmp_path, world):
+    """Frame ranges per rank + halo exchange + gather: `_cls.h5` and `_outputs.csv` byte for byte those of one process, for a
+    clip longer than a chunk, one shorter than the halo on some ranks (7 frames on 3 ranks), a single frame, no frames."""
+    ref_dir, run_dir = str(tmp_path / "ref"), str(tmp_path / "run")
+    rng = np.random.default_rng(11)
+    lengths = {"clipA": 1200, "clipB": 7, "clipC": 1, "clipD": 0, "clipE": 64}
+    for d in (ref_dir, run_dir):
+        os.makedirs(os.path.join(d, "only"))
+    for name, n in lengths.items():
+        fr = rng.integers(0, 200, (n, 8, 8, 3), dtype=np.uint8)
+        for d in (ref_dir, run_dir):
+            np.save(os.path.join(d, name + ".npy"), fr)
+            if name == "clipA":
+                np.save(os.path.join(d, "only", name + ".npy"), fr)
+    P.set_project_stamp("facebook/dinov3-vitb16-pretrain-lvd1689m")
+    try:
+        want = {}
+        for name, n in lengths.items():
+            p = os.path.join(ref_dir, name + ".npy")
+            h5 = P.encode_file(FrameExactEncoder(), p)
+            want[name] = (None, None) if h5 is None else (_sha(h5), _sha(P.infer_file(h5, StubHead(), "gold", NAMES, 31, device="cpu", temperature=0.9)))
+        want_only = _sha(P.encode_file(FrameExactEncoder(), os.path.join(ref_dir, "only", "clipA.npy")))
+    finally:
+        P.set_project_stamp(None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, run_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, enc_only = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for (name, _n), (h5, csv) in zip(sorted(lengths.items()), out):
+        if want[name] == (None, None):
+            assert (h5, csv) == (None, None), name
+        else:
+            assert (_sha(h5), _sha(csv)) == want[name], name
+    assert enc_only[1] is None and _sha(enc_only[0]) == want_only
+

@@ -419,3 +419,72 @@ def test_file_paths_survive_a_workspace_rebuild_and_mixed_clip_sizes(tmp_path):
     finally:
         head.close()
         enc.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One clip split over the ranks (cbas_amd.dist.encode_infer_file_sharded; SURVEY section 8(e), last sentence) on the real kernels
+# ------------------------------------------------------------------------------------------------------------------
+def _sharded_rank(rank, world, port, td, q, backend):
+    import os
+    local = str(rank) if backend == "nccl" else "0"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=local,
+                      LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from cbas_amd import dist as cdist, pipeline as P
+    cdist.init_from_env(backend)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+    cfg, enc, head = _tiny()
+    P.set_project_stamp("enc-id")
+    out = [cdist.encode_infer_file_sharded(os.path.join(td, f), enc, head=head, dataset_name="ds", behaviors=list("abcde"),
+                                           temperature=0.8) for f in ("long.avi", "short.npy")]
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    head.close()
+    enc.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 3), ("nccl", 2)])
+def test_one_clip_split_over_ranks_real_kernels(tmp_path, backend, world):
+    """Every rank decodes and encodes a frame range of the SAME video (Motion-JPEG AVI: random access into a compressed
+    file; and a clip shorter than the head's halo on some ranks), halos are exchanged, rank 0 writes: byte-identical to
+    encode_infer_file on one process.  gloo ranks share the test box's one GPU; the RCCL form needs two."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL path needs two GPUs")
+    import shutil
+    import socket
+    import torch.multiprocessing as mp
+    from cbas_amd import framesource as F, pipeline as P
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    F.write_mjpeg_avi(str(a / "long.avi"), synth.cage_frames(31, 700, 64, 64), quality=90)
+    np.save(str(a / "short.npy"), synth.cage_frames(32, 20, 64, 64))
+    for f in ("long.avi", "short.npy"):
+        shutil.copy(str(a / f), str(b / f))
+    cfg, enc, head = _tiny()
+    P.set_project_stamp("enc-id")
+    try:
+        want = [tuple(_sha(x) for x in P.encode_infer_file(enc, head, str(a / f), "ds", list("abcde"), temperature=0.8))
+                for f in ("long.avi", "short.npy")]
+    finally:
+        P.set_project_stamp(None)
+        head.close()
+        enc.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_rank, args=(r, world, port, str(b), q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [tuple(_sha(x) for x in o) for o in out] == want
+
