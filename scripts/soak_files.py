@@ -65,7 +65,14 @@ def main():
             paths.append((int(k), q))
     res = {"clips": len(paths), "frames": int(sum(lengths[k] for k, _ in paths)), "passes": []}
     ok = True
-    for ps in range(2):
+    n_pass = int(os.environ.get("CBAS_SOAK_PASSES", "2"))
+
+    def rss_mb():
+        for line in open("/proc/self/status"):
+            if line.startswith("VmRSS"):
+                return int(line.split()[1]) / 1024.0
+        return 0.0
+    for ps in range(n_pass):
         t0 = time.perf_counter()
         recs = cdist.encode_files([q for _, q in paths], enc, head=head, dataset_name="soak", behaviors=names)
         dt = time.perf_counter() - t0
@@ -74,7 +81,12 @@ def main():
             if r["status"] != "ok" or (sha(r["cls_file"]), sha(r["csv_file"])) != alone[k]:
                 bad += 1
         ok &= bad == 0
-        res["passes"].append({"seconds": round(dt, 3), "frames_per_s": round(res["frames"] / dt), "clips_differing_from_alone": bad})
+        for r in recs:                                   # the next pass writes the same files again
+            os.remove(r["cls_file"])
+            os.remove(r["csv_file"])
+        free, total = torch.cuda.mem_get_info()
+        res["passes"].append({"seconds": round(dt, 3), "frames_per_s": round(res["frames"] / dt), "clips_differing_from_alone": bad,
+                              "host_rss_mb": round(rss_mb()), "hbm_used_mb": round((total - free) / 2 ** 20)})
         print(res["passes"][-1], flush=True)
     res["all_identical"] = bool(ok)
     head.close()
