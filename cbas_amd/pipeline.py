@@ -93,7 +93,13 @@ class ArrayFrameSource:
 class _DecordSource:
     def __init__(self, path: str):
         import decord  # noqa: WPS433  (present in a CBAS install, absent in the build image)
+        self._path = path
         self._r = decord.VideoReader(path, ctx=decord.cpu(0))   # backend/cbas.py:402
+
+    def clone(self) -> "_DecordSource":
+        """Another decoder instance on the same file: ``_ChunkStream`` runs several, each on every k-th 512-frame chunk
+        (an H.264 decoder is sequential inside a GOP; instances on different parts of the file are what scales)."""
+        return _DecordSource(self._path)
 
     def __len__(self):
         return len(self._r)
@@ -456,25 +462,49 @@ class _ChunkStream:
         self._tokens: dict = {}                      # data address of a delivered chunk -> ring buffer index
         self._stop = threading.Event()
         self._t = None
+        self._ring_lock = threading.Lock()
+        self._readers = [reader]
+        self._ts: list = []
         if not self._direct:
+            # Readers that can be cloned (decord: a sequential H.264 decoder per instance) decode on several instances at
+            # once: instance j takes the 512-frame chunks j, j + k, j + 2k, ... and the consumer takes the chunks in order.
+            k = _decode_readers(reader, self._n)
+            for _ in range(k - 1):
+                try:
+                    self._readers.append(reader.clone())
+                except Exception as e:  # noqa: BLE001 - fewer instances, not a failed encode
+                    print(f"cbas_amd: could not open another decoder instance ({e}); decoding on {len(self._readers)}")
+                    break
+            k = len(self._readers)
             self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
-            self._t = threading.Thread(target=self._run, name="cbas-decode-ahead", daemon=True)
-            self._t.start()
+            self._qs = [self._q] + [queue.Queue(maxsize=max(1, depth)) for _ in range(k - 1)]
+            # every instance may sit on a full queue plus the piece it is decoding; the consumer holds a few more
+            self._ring_depth = (k * (self._q.maxsize + 1) if k > 1 else self._q.maxsize) + 2 + _lib.ENC_SLOTS
+            if k == 1:
+                self._t = threading.Thread(target=self._run, name="cbas-decode-ahead", daemon=True)
+                self._ts = [self._t]
+            else:
+                self._ts = [threading.Thread(target=self._run_strided, args=(j, k), name=f"cbas-decode-ahead-{j}", daemon=True)
+                            for j in range(k)]
+                self._t = self._ts[0]
+            for t in self._ts:
+                t.start()
 
     # -- producer ---------------------------------------------------------------------------------
-    def _put(self, item) -> bool:
+    def _put(self, item, q=None) -> bool:
         import queue
+        q = self._q if q is None else q
         while not self._stop.is_set():
             try:
-                self._q.put(item, timeout=0.1)
+                q.put(item, timeout=0.1)
                 return True
             except queue.Full:
                 continue
         return False
 
-    def _decode(self, i: int, end: int):
+    def _decode(self, i: int, end: int, r=None):
         """One chunk, in a ring buffer when there is one; returns (frames, ring index or None)."""
-        r = self._reader
+        r = self._reader if r is None else r
         if not self._pinned:
             return r.get_batch(range(i, end)), None
         shape = getattr(r, "frame_shape", None)
@@ -482,8 +512,9 @@ class _ChunkStream:
         if shape is None or not hasattr(r, "read_into"):
             arr = r.get_batch(range(i, end))                     # learn the frame shape from the decoder's output
             shape = tuple(arr.shape[1:])
-        if self._ring is None:
-            self._ring = _PinnedRing(self._piece * int(np.prod(shape)), depth=self._q.maxsize + 2 + _lib.ENC_SLOTS)
+        with self._ring_lock:
+            if self._ring is None:
+                self._ring = _PinnedRing(self._piece * int(np.prod(shape)), depth=self._ring_depth)
         k = self._ring.acquire(self._stop)
         if k is None:
             return None, None
@@ -508,6 +539,23 @@ class _ChunkStream:
             if not self._put(item):
                 return
 
+    def _run_strided(self, j: int, k: int):
+        """Decoder instance j of k: every k-th 512-frame chunk, piece by piece, into its own queue."""
+        r, q = self._readers[j], self._qs[j]
+        for c0 in range(j * CHUNK_SIZE, self._n, k * CHUNK_SIZE):
+            for i in range(c0, min(c0 + CHUNK_SIZE, self._n), self._piece):
+                end = min(i + self._piece, self._n)
+                try:
+                    frames, kk = self._decode(i, end, r)
+                    if frames is None:
+                        return
+                    item = (i, end, frames, kk)
+                except BaseException as e:  # noqa: BLE001 - delivered to the consumer in order
+                    self._put((i, end, e, None), q)
+                    return
+                if not self._put(item, q):
+                    return
+
     # -- consumer ---------------------------------------------------------------------------------
     def __iter__(self):
         for i in range(0, self._n, self._piece):
@@ -515,7 +563,9 @@ class _ChunkStream:
                 end = min(i + self._piece, self._n)
                 yield i, end, self._reader.get_batch(range(i, end))
                 continue
-            i, end, frames, k = self._q.get()
+            want = i
+            i, end, frames, k = self._qs[(want // CHUNK_SIZE) % len(self._qs)].get()
+            assert i == want or isinstance(frames, BaseException), (i, want)
             if isinstance(frames, BaseException):
                 raise frames
             if k is not None:
@@ -539,16 +589,38 @@ class _ChunkStream:
         """Stop and JOIN the decode-ahead thread (so that the caller may close the reader afterwards)."""
         self._stop.set()
         if self._t is not None:
-            while True:                                  # unblock a producer waiting on a full queue
+            for q in self._qs:
+                while True:                              # unblock a producer waiting on a full queue
+                    try:
+                        q.get_nowait()
+                    except Exception:  # noqa: BLE001
+                        break
+            for t in self._ts:
+                t.join(timeout=30)
+            self._t, self._ts = None, []
+        for extra in self._readers[1:]:                  # the decoder instances this stream opened itself
+            if hasattr(extra, "close"):
                 try:
-                    self._q.get_nowait()
+                    extra.close()
                 except Exception:  # noqa: BLE001
-                    break
-            self._t.join(timeout=30)
-            self._t = None
+                    pass
+        self._readers = self._readers[:1]
         if self._ring is not None:
             self._ring.give_back()
             self._ring = None
+
+
+def _decode_readers(reader, n_frames: int) -> int:
+    """How many decoder instances ``_ChunkStream`` runs on one file: 1 unless the reader can be cloned; then
+    ``CBAS_DECODE_READERS`` (default 4, at most half the cores), never more than the clip has 512-frame chunks."""
+    if not hasattr(reader, "clone"):
+        return 1
+    try:
+        k = int(os.environ.get("CBAS_DECODE_READERS", "4"))
+    except ValueError:
+        k = 4
+    k = min(k, max(1, (os.cpu_count() or 2) // 2), -(-int(n_frames) // CHUNK_SIZE))
+    return max(1, k)
 
 
 PIECE = 128          # frames per decode-ahead delivery on the GPU paths (see _ChunkStream)

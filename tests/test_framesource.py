@@ -222,3 +222,88 @@ def test_decord_vs_ffmpeg_green_plane_cross_check(tmp_path, monkeypatch, capsys)
     FakePipe.delta = 1
     P.open_video(str(tmp_path / "c.mp4"))
     assert "WARNING" in capsys.readouterr().out and "differs from" not in capsys.readouterr().out
+
+
+class _SlowSeekReader:
+    """A decord-like reader whose decode costs time (GIL released, as libav's does) and which, like an H.264 decoder, pays for a
+    jump: frames from the previous keyframe up to the first requested one are decoded too."""
+    GOP, PER_FRAME = 100, 0.0004
+    opened = 0
+
+    def __init__(self, frames):
+        self._a, self._pos = frames, 0
+        type(self).opened += 1
+        self.closed = False
+
+    def clone(self):
+        return type(self)(self._a)
+
+    def __len__(self):
+        return self._a.shape[0]
+
+    def get_batch(self, indices):
+        import time
+        idx = list(indices)
+        extra = 0 if idx[0] == self._pos else idx[0] % self.GOP          # re-decode from the keyframe after a seek
+        time.sleep((len(idx) + extra) * self.PER_FRAME)
+        self._pos = idx[-1] + 1
+        return self._a[idx[0]:idx[-1] + 1].copy()
+
+    def close(self):
+        self.closed = True
+
+
+def test_cloneable_readers_decode_on_several_instances(monkeypatch):
+    """A reader with ``clone()`` (decord's wrapper) is decoded by several instances, each on every k-th 512-frame chunk: same
+    frames in the same order, the instances the stream opened are closed with it, errors surface at their chunk, and the
+    wall time drops although every jump costs part of a GOP."""
+    import time
+    from cbas_amd import pipeline as P
+    n = 512 * 6 + 77
+    fr = (np.arange(n, dtype=np.uint32)[:, None, None, None] * np.array([1, 3, 7], np.uint32)).astype(np.uint8) * np.ones((1, 4, 4, 1), np.uint8)
+
+    def run(k):
+        monkeypatch.setenv("CBAS_DECODE_READERS", str(k))
+        monkeypatch.setattr(P.os, "cpu_count", lambda: 64)
+        _SlowSeekReader.opened = 0
+        r = _SlowSeekReader(fr)
+        t0 = time.perf_counter()
+        cs = P._chunks(r, n, piece=128)
+        got = [(i, e, f.copy()) for i, e, f in cs]
+        dt = time.perf_counter() - t0
+        extra = cs._readers[1:]
+        cs.close()
+        assert all(x.closed for x in extra) and not r.closed               # the caller's reader is the caller's
+        assert [g[0] for g in got] == list(range(0, n, 128)) and got[-1][1] == n
+        assert np.array_equal(np.concatenate([g[2] for g in got]), fr)
+        return dt, _SlowSeekReader.opened
+
+    t1, o1 = run(1)
+    t4, o4 = run(4)
+    assert o1 == 1 and o4 == 4
+    assert t4 < 0.5 * t1, (t1, t4)                                          # 3 149 frames at 0.4 ms: 1.26 s on one instance
+    # more instances than chunks: capped
+    monkeypatch.setenv("CBAS_DECODE_READERS", "4")
+    _SlowSeekReader.opened = 0
+    small = _SlowSeekReader(fr[:600])
+    cs = P._chunks(small, 600, piece=128)
+    assert len(cs._readers) == 2 and np.array_equal(np.concatenate([f for _i, _e, f in cs]), fr[:600])
+    cs.close()
+
+    class Failing(_SlowSeekReader):
+        def get_batch(self, indices):
+            if 1100 in list(indices):
+                raise IOError("decoder lost sync")
+            return super().get_batch(indices)
+    cs = P._chunks(Failing(fr), n, piece=128)
+    seen = []
+    with pytest.raises(IOError, match="lost sync"):
+        for i, _e, _f in cs:
+            seen.append(i)
+    assert seen == list(range(0, 1024, 128))                                # everything before the bad piece arrived, in order
+    cs.close()
+    # stopping early joins every instance
+    cs = P._chunks(_SlowSeekReader(fr), n, piece=128)
+    next(iter(cs))
+    cs.close()
+    assert cs._ts == []
