@@ -53,7 +53,7 @@ def main(argv=None) -> int:
     ap.add_argument("--split-clips", choices=("auto", "always", "never"), default="auto",
                     help="split EACH video's frames over all GPUs (halo exchange at the cuts) instead of giving each GPU "
                          "whole videos; auto: when there are fewer videos than GPUs")
-    ap.add_argument("--max-batch", type=int, default=64)
+    ap.add_argument("--max-batch", type=int, default=128)
     ap.add_argument("--max-frame", type=int, nargs=2, default=(256, 256))
     ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2),
                     help="0 fp16 (meets the 1e-3 CLS contract), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode "

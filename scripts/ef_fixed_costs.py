@@ -16,7 +16,8 @@ from cbas_amd.encoder import DinoEncoder  # noqa: E402
 from cbas_amd.head import ClassifierLSTMDeltas  # noqa: E402
 
 cfg = C.VIT_B16
-enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(224, 224))
+enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=int(os.environ.get("CBAS_EF_MAX_BATCH", "64")),
+                               max_frame=(224, 224))
 head = ClassifierLSTMDeltas(768, 9)
 head.load_state_dict(W.synth_head_weights(C.HeadConfig(), 4321))
 head.to("cuda")
@@ -41,6 +42,8 @@ for m in (1, 2, 4, 8, 1, 2, 4, 8):
     cdist.encode_files(paths[:m], enc, head=head, dataset_name="x", behaviors=names)
     dt = time.perf_counter() - t0
     print(f"{m} clips: {dt * 1e3:.1f} ms  ({m * n / dt:.0f} frames/s)", flush=True)
+if os.environ.get("CBAS_EF_NO_PROFILE"):
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 cdist.encode_files(paths[:2], enc, head=head, dataset_name="x", behaviors=names)
