@@ -330,6 +330,12 @@ def main() -> None:
     dt_host, host_equal = None, None
     if clip_host is not None:
         run_host_gathered(max(Wm, 1))
+        # the page-locked RESULT buffers of a K-step clip exist before the clock starts, like the page-locked frames do
+        # (torch's caching host allocator hands them out again in finish_host; a first hipHostMalloc of 2 MB costs ~0.6 ms,
+        # which the W-step warm-up - a shorter clip, a smaller block - does not pay for)
+        warm = [torch.empty((K * B, cfg.hidden_size), dtype=torch.float16, pin_memory=True),
+                torch.empty((K * B, BEHAVIORS), dtype=torch.float32, pin_memory=True)]
+        del warm
         dt_host, c16h, prh = timed_host()
         c16d, prd = run(K)                        # the two passes must agree bit for bit
         torch.cuda.synchronize(device)
