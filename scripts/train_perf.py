@@ -1,5 +1,7 @@
 """Head-training throughput: optimisation steps per second on the GPU (cbas_head_train_step, batch 512 as
-in train_lstm_model's default) next to the CPU oracle (torch autograd + Adam restatement) on the host cores."""
+in train_lstm_model's default).  The comparison with the CPU restatement of the same step lives in the test-suite
+(tests/test_gpu_train.py::test_step_rate_next_to_the_cpu_oracle): nothing outside tests/, smoke() and bench.py's CPU leg
+touches oracle/."""
 import os
 import sys
 import time
@@ -13,7 +15,6 @@ from cbas_amd.train import HeadTrainer, initial_head_weights  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-cpu_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 hcfg = C.HeadConfig(in_features=768, out_features=9)
 w0 = initial_head_weights(hcfg, 0)
 x, y = synth.train_windows(1, B, 768, 9, 31)
@@ -30,9 +31,3 @@ dt = (time.perf_counter() - t0) / steps
 loss = tr.step(xt, yt)[0]
 print(f"GPU: batch {B}: {dt * 1e3:.3f} ms/step, {B / dt:.0f} windows/s (loss after {steps + 4} steps {loss:.4f})", flush=True)
 tr.close()
-if cpu_steps > 0:
-    from oracle import head_train_oracle as HT
-    t0 = time.perf_counter()
-    HT.train_steps([x], [y], w0, cpu_steps, 1e-4, 1)
-    dc = (time.perf_counter() - t0) / cpu_steps
-    print(f"CPU oracle (torch {torch.get_num_threads()} threads): {dc * 1e3:.1f} ms/step, {B / dc:.0f} windows/s -> GPU/CPU {dc / dt:.1f}x")

@@ -207,3 +207,34 @@ def test_other_shapes_against_oracle(I, Cn, T, h, nl, B, acc):
         scale = max(np.abs(rg[name]).max(), 1e-6)
         floor = 5e-6 if name == "attention_head.bias" else 2e-7
         assert np.abs(grads[name] - rg[name]).max() <= 4e-4 * scale + floor, (name, float(np.abs(grads[name] - rg[name]).max()), float(scale))
+
+
+def test_step_rate_next_to_the_cpu_oracle(capsys):
+    """Optimisation steps per second of cbas_head_train_step (batch 512, train_lstm_model's default) next to the CPU
+    restatement of the same step (torch autograd + Adam) on the host cores: a reported ratio, asserted only to be > 1."""
+    import time
+    from oracle import head_train_oracle as HT
+    from cbas_amd.train import HeadTrainer, initial_head_weights
+    B, steps, cpu_steps = 512, 30, 2
+    hcfg = C.HeadConfig(in_features=768, out_features=9)
+    w0 = initial_head_weights(hcfg, 0)
+    x, y = synth.train_windows(1, B, 768, 9, 31)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    tr = HeadTrainer(hcfg, w0, "cuda", lr=1e-4, max_batch=B, seed=1)
+    for _ in range(3):
+        tr.step(xt, yt, want_loss=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(xt, yt, want_loss=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tr.close()
+    t0 = time.perf_counter()
+    HT.train_steps([x], [y], w0, cpu_steps, 1e-4, 1)
+    dc = (time.perf_counter() - t0) / cpu_steps
+    with capsys.disabled():
+        print(f"\nhead training, batch {B}: GPU {dt * 1e3:.2f} ms/step ({B / dt:.0f} windows/s); CPU restatement on "
+              f"{torch.get_num_threads()} threads {dc * 1e3:.0f} ms/step -> {dc / dt:.0f}x")
+    assert dc > dt
+
