@@ -469,13 +469,7 @@ class _ChunkStream:
             # Readers that can be cloned (decord: a sequential H.264 decoder per instance) decode on several instances at
             # once: instance j takes the 512-frame chunks j, j + k, j + 2k, ... and the consumer takes the chunks in order.
             k = _decode_readers(reader, self._n)
-            for _ in range(k - 1):
-                try:
-                    self._readers.append(reader.clone())
-                except Exception as e:  # noqa: BLE001 - fewer instances, not a failed encode
-                    print(f"cbas_amd: could not open another decoder instance ({e}); decoding on {len(self._readers)}")
-                    break
-            k = len(self._readers)
+            self._readers += [None] * (k - 1)             # opened by their own threads: the first chunk does not wait for them
             self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
             self._qs = [self._q] + [queue.Queue(maxsize=max(1, depth)) for _ in range(k - 1)]
             # every instance may sit on a full queue plus the piece it is decoding; the consumer holds a few more
@@ -541,7 +535,15 @@ class _ChunkStream:
 
     def _run_strided(self, j: int, k: int):
         """Decoder instance j of k: every k-th 512-frame chunk, piece by piece, into its own queue."""
-        r, q = self._readers[j], self._qs[j]
+        q = self._qs[j]
+        if self._readers[j] is None:
+            try:
+                self._readers[j] = self._reader.clone()
+            except BaseException as e:  # noqa: BLE001 - this instance's first chunk carries the error
+                i = j * CHUNK_SIZE
+                self._put((i, min(i + self._piece, self._n), e, None), q)
+                return
+        r = self._readers[j]
         for c0 in range(j * CHUNK_SIZE, self._n, k * CHUNK_SIZE):
             for i in range(c0, min(c0 + CHUNK_SIZE, self._n), self._piece):
                 end = min(i + self._piece, self._n)
@@ -599,7 +601,7 @@ class _ChunkStream:
                 t.join(timeout=30)
             self._t, self._ts = None, []
         for extra in self._readers[1:]:                  # the decoder instances this stream opened itself
-            if hasattr(extra, "close"):
+            if extra is not None and hasattr(extra, "close"):
                 try:
                     extra.close()
                 except Exception:  # noqa: BLE001

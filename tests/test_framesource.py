@@ -271,9 +271,9 @@ def test_cloneable_readers_decode_on_several_instances(monkeypatch):
         cs = P._chunks(r, n, piece=128)
         got = [(i, e, f.copy()) for i, e, f in cs]
         dt = time.perf_counter() - t0
-        extra = cs._readers[1:]
+        extra = [x for x in cs._readers[1:]]
         cs.close()
-        assert all(x.closed for x in extra) and not r.closed               # the caller's reader is the caller's
+        assert all(x is not None and x.closed for x in extra) and not r.closed      # the caller's reader is the caller's
         assert [g[0] for g in got] == list(range(0, n, 128)) and got[-1][1] == n
         assert np.array_equal(np.concatenate([g[2] for g in got]), fr)
         return dt, _SlowSeekReader.opened
