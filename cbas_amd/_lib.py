@@ -64,6 +64,8 @@ SIGNATURES = {
                                   C.POINTER(c_int64), c_void_p]),
     "cbas_fused_finish_async": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_int64)]),
     "cbas_fused_wait": (c_int, [c_void_p]),
+    "cbas_fused_stream_rows": (c_int, [c_void_p, c_void_p]),
+    "cbas_fused_rows_ready": (c_int64, [c_void_p, c_int32]),
     "cbas_enc_set_lanes": (c_int, [c_void_p, c_int]),
     "cbas_enc_set_prune_last_layer": (c_int, [c_void_p, c_int]),
     "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,

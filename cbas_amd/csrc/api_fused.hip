@@ -8,7 +8,9 @@
 // alternate over the encoder's slots / compute lanes, a segment of frames is classified as soon as its
 // right-hand context (seq_len/2 rows) has been encoded by batches the session's stream is already ordered
 // after, in groups of `classify_every` frames, so the head never drains the encoder lanes mid-clip.
+#include <atomic>
 #include <new>
+#include <thread>
 
 #include "api_common.h"
 
@@ -33,6 +35,15 @@ struct cbas_fused {
     uint64_t seq = 0;
     hipEvent_t clip_done = nullptr; // recorded on st when a clip's last operation (tail classify, copy-out) has been queued
     bool clip_pending = false;
+    // rows copied out WHILE the clip runs (cbas_fused_stream_rows): every STREAM_STEP landed rows one device->host copy on st
+    // with an event; a single consumer thread (the file writer) follows them through cbas_fused_rows_ready
+    static constexpr int NT = 128;
+    static constexpr int64_t STREAM_STEP = 512;
+    struct Ticket { hipEvent_t ev = nullptr; int64_t upto = 0; } tickets[NT];
+    std::atomic<uint64_t> n_tickets{0}, consumed{0};
+    std::atomic<int64_t> ready_rows{0};
+    uint16_t* stream_host = nullptr;
+    int64_t copied = 0;
 };
 
 namespace {
@@ -49,6 +60,22 @@ int drain(cbas_fused* f) {
         f->landed += f->busy[best].n;
         f->busy[best].n = 0;
     }
+}
+
+// queue the device->host copy of the landed rows [copied, upto) and publish its ticket
+int queue_row_copy(cbas_fused* f, int64_t upto) {
+    if (!f->stream_host || upto <= f->copied) return CBAS_OK;
+    const uint64_t n = f->n_tickets.load(std::memory_order_relaxed);
+    if (n - f->consumed.load(std::memory_order_acquire) >= (uint64_t)cbas_fused::NT) return CBAS_OK;   // consumer far behind: later
+    cbas_fused::Ticket& t = f->tickets[n % cbas_fused::NT];
+    if (!t.ev) HIP_TRY(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(f->stream_host + f->copied * f->D, f->cls16 + f->copied * f->D, (size_t)(upto - f->copied) * f->D * 2,
+                           hipMemcpyDeviceToHost, f->st));
+    HIP_TRY(hipEventRecord(t.ev, f->st));
+    t.upto = upto;
+    f->copied = upto;
+    f->n_tickets.store(n + 1, std::memory_order_release);
+    return CBAS_OK;
 }
 
 int classify(cbas_fused* f, int64_t count, int64_t n_rows) {
@@ -88,6 +115,10 @@ int push(cbas_fused* f, const uint8_t* frames, bool host, int n, int height, int
         f->busy[slot].n = m;
         f->busy[slot].seq = ++f->seq;
         f->encoded += m;
+    }
+    if (f->stream_host && f->landed - f->copied >= cbas_fused::STREAM_STEP) {
+        int rc = queue_row_copy(f, f->landed);
+        if (rc) return rc;
     }
     const int64_t ready = f->landed - f->half - f->classified;       // frames with their full right context
     if (ready >= f->classify_every) return classify(f, ready, f->landed);
@@ -142,6 +173,8 @@ extern "C" void cbas_fused_destroy(cbas_fused* f) {
     (void)drain(f);
     if (f->st) { (void)hipStreamSynchronize(f->st); if (f->own_stream) (void)hipStreamDestroy(f->st); }
     if (f->clip_done) (void)hipEventDestroy(f->clip_done);
+    for (auto& t : f->tickets)
+        if (t.ev) (void)hipEventDestroy(t.ev);
     if (f->cls16) (void)hipFree(f->cls16);
     if (f->probs) (void)hipFree(f->probs);
     delete f;
@@ -158,7 +191,36 @@ extern "C" int cbas_fused_reset(cbas_fused* f) {
     if (f->clip_pending) { HIP_TRY(hipEventSynchronize(f->clip_done)); f->clip_pending = false; }
     else if (f->encoded > 0) HIP_TRY(hipStreamSynchronize(f->st));          // a clip that was never finished
     f->encoded = f->classified = f->landed = 0;
+    f->stream_host = nullptr;                                           // (its consumer is done: the caller joined it)
+    f->copied = 0;
+    f->n_tickets.store(0); f->consumed.store(0); f->ready_rows.store(0);
     return CBAS_OK;
+}
+
+extern "C" int cbas_fused_stream_rows(cbas_fused* f, uint16_t* cls_f16_host) {
+    if (!f) return cbas_fail(CBAS_EINVAL, "null session");
+    if (f->encoded != 0 || f->n_tickets.load() != 0) return cbas_fail(CBAS_ESTATE, "cbas_fused_stream_rows: call it right after cbas_fused_reset");
+    f->stream_host = cls_f16_host;
+    return CBAS_OK;
+}
+
+extern "C" int64_t cbas_fused_rows_ready(cbas_fused* f, int32_t block) {
+    if (!f) return -1;
+    if (hipSetDevice(f->device) != hipSuccess) return -1;
+    const uint64_t n = f->n_tickets.load(std::memory_order_acquire);
+    uint64_t c = f->consumed.load(std::memory_order_relaxed);
+    int64_t ready = f->ready_rows.load(std::memory_order_relaxed);
+    bool wait = block != 0;
+    while (c < n) {
+        const cbas_fused::Ticket& t = f->tickets[c % cbas_fused::NT];
+        if (wait) { if (hipEventSynchronize(t.ev) != hipSuccess) return -1; wait = false; }
+        else if (hipEventQuery(t.ev) != hipSuccess) { (void)hipGetLastError(); break; }
+        ready = t.upto;
+        ++c;
+    }
+    f->ready_rows.store(ready, std::memory_order_relaxed);
+    f->consumed.store(c, std::memory_order_release);
+    return ready;
 }
 
 extern "C" int cbas_fused_push_u8_host(cbas_fused* f, const uint8_t* frames_host, int n, int height, int width,
@@ -183,7 +245,14 @@ int finish_impl(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const 
         rc = classify(f, f->encoded - f->classified, f->encoded);      // the clip's right edge replicates its last row
         if (rc) return rc;
     }
-    if (cls_f16_host)
+    if (f->stream_host) {                                               // rows have been leaving all along: the rest
+        // (a consumer that fell NT tickets behind makes queue_row_copy skip: wait for it, the clip is over anyway)
+        while (f->copied < f->encoded) {
+            rc = queue_row_copy(f, f->encoded);
+            if (rc) return rc;
+            if (f->copied < f->encoded) std::this_thread::yield();
+        }
+    } else if (cls_f16_host)
         HIP_TRY(hipMemcpyAsync(cls_f16_host, f->cls16, (size_t)f->encoded * f->D * 2, hipMemcpyDeviceToHost, f->st));
     if (probs_host && f->C > 0)
         HIP_TRY(hipMemcpyAsync(probs_host, f->probs, (size_t)f->encoded * f->C * 4, hipMemcpyDeviceToHost, f->st));

@@ -293,8 +293,8 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
         # the same bytes (tests/test_host_logic.py), `.tmp` + rename as ever, +4 % over the per-batch copy-out of the
         # slot loop below (which stays for stand-in encoders and as CBAS_ENCODE_FILE_SLOTS=1)
         try:
-            res = _runner_for(encoder, None, 1.0).run(path, reader, progress_callback)
-            out = write_cls_file(path, res.rows, file_attrs(encoder))
+            out = _write_cls_while_encoding(path, encoder, lambda sink: _runner_for(encoder, None, 1.0).run(
+                path, reader, progress_callback, rows_sink=sink))[0]
         except Exception as e:
             print(f"ERROR during encoding for {path}: {e}")
             raise
@@ -328,6 +328,27 @@ def _encode_from_reader(encoder: DinoEncoder, path: str, reader, progress_callba
                 except OSError:
                     pass
         raise e
+
+
+def _write_cls_while_encoding(video_path: str, encoder, run):
+    """``<video>_cls.h5`` with encode_file's file semantics (``.tmp`` first, stamp attributes, atomic rename, the ``.tmp``
+    removed on failure: backend/cbas.py:410-421, 442-456), its rows arriving from ``run(sink)`` while the clip is encoded.
+    Returns (path, what run returned)."""
+    out_file_path = os.path.splitext(video_path)[0] + "_cls.h5"
+    tmp_file_path = out_file_path + ".tmp"
+    try:
+        with h5io.ClsWriter(tmp_file_path, encoder.config.hidden_size, file_attrs(encoder)) as w:
+            res = run(w)
+            w.flush()
+        os.replace(tmp_file_path, out_file_path)
+    except BaseException:
+        if os.path.exists(tmp_file_path):
+            try:
+                os.remove(tmp_file_path)
+            except OSError:
+                pass
+        raise
+    return out_file_path, res
 
 
 class _MemWriter:
@@ -805,9 +826,11 @@ class ClipRunner:
             if own_reader and hasattr(reader, "close"):
                 reader.close()
 
-    def run(self, path: str, reader=None, progress_callback=None, device_out: bool = False) -> Optional[ClipResult]:
+    def run(self, path: str, reader=None, progress_callback=None, device_out: bool = False, rows_sink=None) -> Optional[ClipResult]:
         """Encode (and classify) one video; ``None`` for a video without frames.  Reader / encoder errors propagate with
-        the encoder left reusable."""
+        the encoder left reusable.  ``rows_sink`` (an object with ``append(rows)``, e.g. ``h5io.ClsWriter``): the fp16 rows are
+        handed to it in order WHILE the clip runs, from a helper thread (cbas_fused_stream_rows) - the file is all but
+        written when the last batch ends, as with the reference's per-chunk writes (backend/cbas.py:436-440)."""
         if not self.native:
             rows = encode_rows(self.encoder, path, progress_callback, reader)
             if rows is None:
@@ -815,6 +838,8 @@ class ClipRunner:
             probs = None
             if self.head is not None and rows.shape[0] > 0:
                 probs = self.head.infer_clip(torch.from_numpy(rows), self.temperature).cpu().numpy()
+            if rows_sink is not None:
+                rows_sink.append(rows)
             return ClipResult(rows, probs, False)
         own_reader = reader is None
         reader = reader if reader is not None else open_video(path)
@@ -823,14 +848,16 @@ class ClipRunner:
             if video_len == 0:
                 print(f"Warning: Video {path} contains no frames. Skipping.")
                 return None
-            return self._run_native(reader, video_len, progress_callback, device_out)
+            return self._run_native(reader, video_len, progress_callback, device_out, rows_sink=rows_sink)
         finally:
             if own_reader and hasattr(reader, "close"):
                 reader.close()
 
-    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool, wait: bool = True, chunks=None):
+    def _run_native(self, reader, video_len: int, progress_callback, device_out: bool, wait: bool = True, chunks=None,
+                    rows_sink=None):
         enc = self.encoder
         ent = None
+        pump = None
         sub = 0                                      # sub-batches submitted so far
         held: deque = deque()                        # (chunk frames, sub-batch count after which its copies are done)
         if chunks is None:
@@ -842,7 +869,15 @@ class ClipRunner:
                 if ent is None:
                     enc._fit_frame(frames.shape[1], frames.shape[2])     # may rebuild the handle (closes sessions)
                     ent = self._session(video_len)
-                ent[0].push_host(frames, channel=1)                      # green channel, cbas.py:431
+                    if rows_sink is not None and wait and not device_out and os.environ.get("CBAS_ROWS_STREAM") != "0":
+                        ent[0].stream_rows_to(video_len)
+                        pump = _RowsPump(ent[0], rows_sink)
+                try:
+                    ent[0].push_host(frames, channel=1)                  # green channel, cbas.py:431
+                except BaseException:
+                    if pump is not None:
+                        pump.abort()
+                    raise
                 sub += -(-frames.shape[0] // enc.max_batch)
                 # a slot's previous host->HBM copy has completed when the slot is submitted to again, i.e. ENC_SLOTS
                 # sub-batches later (cbas_enc_submit_u8_host_dev): only then may the decoder refill this chunk's buffer
@@ -862,11 +897,56 @@ class ClipRunner:
                 torch.cuda.current_stream(enc.device).synchronize()      # every copy out of the ring has completed
                 res = ClipResult(rows, probs if self.head is not None else None, True, ent[1])
             else:
-                rows, probs = sess.finish_host()
+                try:
+                    rows, probs = sess.finish_host()
+                except BaseException:
+                    if pump is not None:
+                        pump.abort()
+                    raise
+                if pump is not None:
+                    pump.finish(rows.shape[0])                           # the sink has every row now (its error surfaces here)
+                elif rows_sink is not None:
+                    rows_sink.append(rows)
                 res = ClipResult(rows, probs if self.head is not None else None, False)
             while held:
                 chunks.release(held.popleft()[0])
         return res
+
+
+class _RowsPump:
+    """Follows a session's progressive row copies (``ClipStream.rows_ready``) on a helper thread and appends the rows to a
+    sink in order; ``finish(n)`` returns when all n rows are in the sink, ``abort()`` when the thread has stopped."""
+
+    def __init__(self, sess, sink):
+        self._sess, self._sink = sess, sink
+        self._have, self._total, self._stop, self._err = 0, None, False, None
+        self._t = threading.Thread(target=self._run, name="cbas-rows-out", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        import time
+        try:
+            while not self._stop:
+                r = self._sess.rows_ready(block=True)
+                if r > self._have:
+                    self._sink.append(self._sess._stream_rows[self._have:r])
+                    self._have = r
+                elif self._total is not None and self._have >= self._total:
+                    return
+                else:
+                    time.sleep(0.0005)
+        except BaseException as e:  # noqa: BLE001 - re-raised by finish()
+            self._err = e
+
+    def finish(self, total: int) -> None:
+        self._total = int(total)
+        self._t.join()
+        if self._err is not None:
+            raise self._err
+
+    def abort(self) -> None:
+        self._stop = True
+        self._t.join()
 
 
 class _PreparedClip:
@@ -935,10 +1015,17 @@ def encode_infer_file(encoder: DinoEncoder, model, path: str, dataset_name: str,
     head = _as_mi355x_head(model, encoder.device)
     if len(behaviors) != head.out_features:
         raise ValueError(f"{len(behaviors)} behaviour names for {head.out_features} model outputs")
-    res = _runner_for(encoder, head, temperature).run(path, reader, progress_callback)
-    if res is None:
-        return None, None
-    cls_path = write_cls_file(path, res.rows, file_attrs(encoder))
+    own_reader = reader is None
+    reader = reader if reader is not None else open_video(path)
+    try:
+        if len(reader) == 0:
+            print(f"Warning: Video {path} contains no frames. Skipping.")
+            return None, None
+        cls_path, res = _write_cls_while_encoding(path, encoder, lambda sink: _runner_for(encoder, head, temperature).run(
+            path, reader, progress_callback, rows_sink=sink))
+    finally:
+        if own_reader and hasattr(reader, "close"):
+            reader.close()
     print(f"Successfully encoded {os.path.basename(path)} to {os.path.basename(cls_path)}")
     csv_path = cls_path.replace("_cls.h5", f"_{dataset_name}_outputs.csv")
     write_probs_csv(csv_path, res.probs, list(behaviors))

@@ -78,6 +78,7 @@ class ClipStream:
         _lib.check(self._lib.cbas_fused_reset(self._h), "cbas_fused_reset")
         self._keep = []
         self.encoded = 0
+        self._stream_rows = None
 
     def push_u8(self, frames: torch.Tensor, channel: int = 1) -> None:
         """Append uint8 frames resident in HBM ((n,H,W,3) or (n,H,W)); classifies every frame whose window is
@@ -138,6 +139,22 @@ class ClipStream:
         assert int(n.value) == self.encoded
         return o16, opr, _ClipWait(self)
 
+    def stream_rows_to(self, n_rows: int) -> np.ndarray:
+        """Right after ``reset``: rows leave for a page-locked (n_rows, D) float16 array WHILE the clip runs
+        (``cbas_fused_stream_rows``); returns that array.  ``rows_ready`` says how many leading rows are complete;
+        ``finish_host`` then copies only the remainder and returns the same array."""
+        D = self.enc.config.hidden_size
+        self._stream_rows = torch.empty((int(n_rows), D), dtype=torch.float16, pin_memory=True).numpy()
+        _lib.check(self._lib.cbas_fused_stream_rows(self._h, self._stream_rows.ctypes.data), "cbas_fused_stream_rows")
+        return self._stream_rows
+
+    def rows_ready(self, block: bool = False) -> int:
+        """Leading rows complete in the ``stream_rows_to`` array (one consumer thread; may run beside pushes)."""
+        r = int(self._lib.cbas_fused_rows_ready(self._h, 1 if block else 0))
+        if r < 0:
+            raise RuntimeError("cbas_fused_rows_ready failed")
+        return r
+
     def wait(self) -> None:
         """Block until the clip queued by ``finish_host_async`` is complete."""
         if self._h:
@@ -149,7 +166,12 @@ class ClipStream:
         # page-locked destinations: a device -> PAGEABLE host copy goes through the runtime's slow staged path (measured:
         # 7.7 ms for 4 MB, i.e. ~30 ms of a 10 000-frame clip's 460 ms - most of what the host path lost against
         # HBM-resident frames in round 2); torch's caching host allocator makes these allocations cheap after the first
-        o16 = torch.empty((self.encoded, D), dtype=torch.float16, pin_memory=True).numpy()
+        streamed = getattr(self, "_stream_rows", None)
+        if streamed is not None:
+            assert streamed.shape[0] >= self.encoded
+            o16 = streamed[:self.encoded]
+        else:
+            o16 = torch.empty((self.encoded, D), dtype=torch.float16, pin_memory=True).numpy()
         opr = torch.empty((self.encoded, Cn), dtype=torch.float32, pin_memory=True).numpy() if Cn else np.empty((self.encoded, 0), np.float32)
         n = C.c_int64(0)
         _lib.check(self._lib.cbas_fused_finish(self._h, o16.ctypes.data, opr.ctypes.data if Cn else None, None, None,

@@ -311,6 +311,15 @@ int cbas_fused_finish(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, 
  * legacy NULL stream, hipStreamWaitEvent blocks the HOST until the event has completed, 15 ms at the end of every clip.) */
 int cbas_fused_finish_async(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, int64_t* n_frames);
 int cbas_fused_wait(cbas_fused* f);
+/* Rows out WHILE the clip runs - what encode_file's per-chunk `dset[...] = ...; f.flush()` is to the reference
+ * (backend/cbas.py:436-440): called right after cbas_fused_reset with a page-locked buffer for the whole clip, it makes
+ * the session copy CLS rows to it as their batches land (one device->host copy per 512 rows, queued behind the batches
+ * that produce them); cbas_fused_finish then copies only the remainder (its cls_f16_host is ignored).  ONE consumer thread -
+ * the file writer - follows with cbas_fused_rows_ready(f, block): the number R of leading rows that are complete in the
+ * buffer (block != 0: waits for the next queued copy if there is one); it may run concurrently with pushes.  With this the
+ * `_cls.h5` of a clip is all but written when its last batch ends (the file write was 21-26 ms of an 18 000-frame clip). */
+int cbas_fused_stream_rows(cbas_fused* f, uint16_t* cls_f16_host);
+int64_t cbas_fused_rows_ready(cbas_fused* f, int32_t block);
 
 /* ---- head training -------------------------------------------------------------------------
  * Replaces the optimisation step inside train_lstm_model (backend/cbas.py:1326-1348):
