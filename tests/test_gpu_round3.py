@@ -251,6 +251,52 @@ def test_encode_files_survives_bad_clips_opened_ahead(tmp_path):
         enc.close()
 
 
+def test_rows_leave_while_the_clip_runs(tmp_path, monkeypatch):
+    """encode_file / encode_infer_file append the rows to the `.tmp` HDF5 file from a helper thread while the clip is encoded
+    (cbas_fused_stream_rows): same bytes as the one-append form (CBAS_ROWS_STREAM=0), several appends actually happen, and a
+    writer that fails in the middle fails the call the reference's way - exception out, no `.tmp`, no `_cls.h5`, encoder
+    usable again."""
+    from cbas_amd import h5io, pipeline as P
+    cfg, enc, head = _tiny()
+    try:
+        p = str(tmp_path / "clip.npy")
+        np.save(p, synth.cage_frames(21, 3000, 64, 64))
+        appends = []
+        real_append = h5io.ClsWriter.append
+
+        def counting(self, rows):
+            appends.append(len(rows))
+            return real_append(self, rows)
+        monkeypatch.setattr(h5io.ClsWriter, "append", counting)
+        a = _sha(P.encode_file(enc, p))
+        assert sum(appends) == 3000 and len(appends) >= 3, appends          # 512-row pieces while the clip ran + the tail
+        h5, csv = P.encode_infer_file(enc, head, p, "m", list("abcde"))
+        pair = (_sha(h5), _sha(csv))
+        monkeypatch.setenv("CBAS_ROWS_STREAM", "0")
+        appends.clear()
+        assert _sha(P.encode_file(enc, p)) == a and appends == [3000]
+        h5, csv = P.encode_infer_file(enc, head, p, "m", list("abcde"))
+        assert (_sha(h5), _sha(csv)) == pair and pair[0] == a
+        monkeypatch.delenv("CBAS_ROWS_STREAM")
+        os.remove(h5)
+
+        def failing(self, rows):
+            if sum(appends) >= 1024:
+                raise OSError("disk full")
+            appends.append(len(rows))
+            return real_append(self, rows)
+        appends.clear()
+        monkeypatch.setattr(h5io.ClsWriter, "append", failing)
+        with pytest.raises(OSError, match="disk full"):
+            P.encode_file(enc, p)
+        assert not os.path.exists(str(tmp_path / "clip_cls.h5")) and not os.path.exists(str(tmp_path / "clip_cls.h5.tmp"))
+        monkeypatch.setattr(h5io.ClsWriter, "append", real_append)
+        assert _sha(P.encode_file(enc, p)) == a
+    finally:
+        head.close()
+        enc.close()
+
+
 def test_encode_file_on_a_compressed_video_equals_its_decoded_frames(tmp_path):
     """Motion-JPEG AVI (real decoder work on the decode-ahead thread, frames landing in the page-locked ring) against the same
     decoded frames stored as .npy: identical `_cls.h5` rows and identical probabilities."""
