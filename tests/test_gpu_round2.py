@@ -433,7 +433,7 @@ def _dist_rank(rank, world, port, td, q, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+@pytest.mark.parametrize("backend", ["gloo"])        # the RCCL form: tests/test_zz_rccl_two_gpus.py (runs last, needs two GPUs)
 def test_encode_files_two_ranks_real_kernels(tmp_path, backend):
     """Two processes driving the real encoder / head: rank 0's files are byte-identical to the single-process encode_file /
     infer_file results.  gloo: both ranks on the one GPU.  nccl (RCCL over xGMI, device-to-device point-to-point transfers
@@ -467,10 +467,16 @@ def test_encode_files_two_ranks_real_kernels(tmp_path, backend):
     procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, str(b), q, backend)) for r in range(2)]
     for p in procs:
         p.start()
-    recs = q.get(timeout=240)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        recs = q.get(timeout=240)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:                                     # a rank that hangs (first contact with RCCL) must not outlive the test
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
     assert [r["status"] for r in recs] == ["ok", "empty", "ok", "ok", "ok"]
     for r, e in zip(recs, exp):
         if e is not None:

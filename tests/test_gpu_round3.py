@@ -492,7 +492,7 @@ def _sharded_rank(rank, world, port, td, q, backend):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 3), ("nccl", 2)])
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 3)])      # RCCL form: tests/test_zz_rccl_two_gpus.py
 def test_one_clip_split_over_ranks_real_kernels(tmp_path, backend, world):
     """Every rank decodes and encodes a frame range of the SAME video (Motion-JPEG AVI: random access into a compressed
     file; and a clip shorter than the head's halo on some ranks), halos are exchanged, rank 0 writes: byte-identical to
@@ -528,9 +528,15 @@ def test_one_clip_split_over_ranks_real_kernels(tmp_path, backend, world):
     procs = [ctx.Process(target=_sharded_rank, args=(r, world, port, str(b), q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=240)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        out = q.get(timeout=240)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:                                     # a rank that hangs (first contact with RCCL) must not outlive the test
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
     assert [tuple(_sha(x) for x in o) for o in out] == want
 
