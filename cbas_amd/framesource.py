@@ -272,7 +272,7 @@ def _riff_chunks(buf, start: int, end: int):
     p = start
     while p + 8 <= end:
         cc, size = buf[p:p + 4], struct.unpack_from("<I", buf, p + 4)[0]
-        yield bytes(cc), p + 8, size
+        yield bytes(cc), p + 8, min(size, end - (p + 8))      # a truncated file: never hand out bytes past its end
         p += 8 + size + (size & 1)
 
 

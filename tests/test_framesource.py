@@ -169,6 +169,21 @@ def test_mjpeg_avi_round_trip_and_decode_ahead(tmp_path):
         r2 = F.MJPEGAviSource(p, **kw)
         assert np.array_equal(r2.get_batch(range(70)), allf), kw
         r2.close()
+    # a file cut in the middle of a frame (a recording that was interrupted): the frames before the cut decode, the cut
+    # one is a decode error - from both decoders - and nothing reads past the end of the mapping
+    whole = open(p, "rb").read()
+    src = F.MJPEGAviSource(p)
+    off40, size40 = src._frames[40]
+    src.close()
+    cut = str(tmp_path / "cut.avi")
+    open(cut, "wb").write(whole[:off40 + size40 // 2])
+    for kw in ({"native": True}, {"native": False}):
+        r3 = F.MJPEGAviSource(cut, planes=True, **kw)
+        assert len(r3) == 41
+        assert np.array_equal(r3.get_batch(range(40)), allf[:40, :, :, 1])
+        with pytest.raises(Exception):
+            r3.get_batch(range(36, 41))
+        r3.close()
     # not Motion-JPEG -> refused (open_video then goes on to the ffmpeg pipe, or reports that nothing can read it)
     raw = bytearray(open(p, "rb").read())
     i = raw.find(b"vidsMJPG")
