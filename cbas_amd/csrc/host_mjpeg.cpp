@@ -298,6 +298,7 @@ bool Decoder::scan(const uint8_t* p, const uint8_t* end) {
                         int s = br.decode(hd);
                         if (s < 0 || s > 11) return fail("bad DC code");
                         if (s) k.pred += br.receive_extend(s);
+                        if (k.pred > 32767 || k.pred < -32768) return fail("DC coefficient out of range");
                         int last = 0;
                         bool cleared = false;
                         for (int i = 1; i < 64;) {
