@@ -166,6 +166,24 @@ def test_e2e_config1_golden(golden_dir):
     assert (probs.argmax(1) == g["labels"]).all()
 
 
+def test_e2e_config2_model_golden(golden_dir):
+    """The headline model through the reference's own DinoEncoder wrapper + infer_file (ViT-B/16, 256 frames, C = 9): the
+    torch restatement on the first 24 frames, the head restatement on all the golden fp16 rows."""
+    g = load(golden_dir, "e2e_vitb16")
+    n = int(g["n"])
+    fr = synth.cage_frames(int(g["frame_seed"]), n, 224, 224)
+    assert sha(fr) == str(g["frames_sha"])
+    from oracle import vit_oracle_torch as VT
+    cfg = C.VIT_B16
+    cls32 = VT.encode_frames(fr[:24], VT.to_torch(W.synth_encoder_weights(cfg, 1234)), cfg, batch=8)
+    rel = np.linalg.norm(cls32 - g["cls"][:24], axis=1) / np.linalg.norm(g["cls"][:24], axis=1)
+    assert rel.max() < 1e-5
+    assert np.array_equal(g["cls"].astype(np.float16), g["cls_f16"])                  # h5py's f4 -> f2 cast (cbas.py:438)
+    probs = PO.classify_cls(g["cls_f16"], W.synth_head_weights(C.HeadConfig(in_features=768), 4321), 31, 1.0)
+    np.testing.assert_allclose(probs, g["probs"], atol=1e-5)
+    assert (probs.argmax(1) == g["labels"]).all() and len(set(g["labels"].tolist())) >= 2
+
+
 @pytest.mark.parametrize("name,cfgname,hw", [("vitb16_224_noise", "vitb16", 224), ("vitb16_256", "vitb16", 256)])
 def test_torch_restatement_against_reference_goldens(golden_dir, name, cfgname, hw):
     """oracle/vit_oracle_torch.py (what bench.py times as cpu_baseline) against CLS rows made by the reference."""
