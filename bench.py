@@ -121,6 +121,26 @@ def gates(enc, head, model: str, hw: int, precision: int) -> dict:
         ref = g["probs_700"]
         out.update(head_label_mismatches=int((pr.argmax(1) != ref.argmax(1)).sum()), head_frames=700,
                    head_prob_err_max=float(f"{np.abs(pr - ref).max():.3e}"), head_fixture="infer_file.npz[probs_700]")
+    # end to end on the headline model: frames -> this encoder -> f16 rows -> this head, against the reference's own
+    # DinoEncoder wrapper + infer_file (tests/golden/e2e_vitb16.npz, 256 frames)
+    ep = os.path.join(gd, "e2e_vitb16.npz")
+    if os.path.exists(ep) and (model, hw) == ("vitb16", 224) and head.in_features == 768 and head.out_features == BEHAVIORS:
+        g = np.load(ep)
+        fr = synth.cage_frames(int(g["frame_seed"]), int(g["n"]), hw, hw)
+        c16, _ = enc.encode_u8(torch.from_numpy(fr).to(enc.device), want_f32=False)
+        pr = head.infer_clip(c16, 1.0).cpu().numpy().astype(np.float64)
+        ref = g["probs"].astype(np.float64)
+        srt = np.sort(ref, axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        flips = np.nonzero(pr.argmax(1) != ref.argmax(1))[0]
+        c = c16.float().cpu().numpy().astype(np.float64)
+        rc = g["cls"].astype(np.float64)
+        rel = np.linalg.norm(c - rc, axis=1) / np.linalg.norm(rc, axis=1)
+        out["e2e"] = {"fixture": "e2e_vitb16.npz", "frames": int(len(ref)), "label_mismatches": int(len(flips)),
+                      "largest_reference_margin_at_a_mismatch": float(f"{margin[flips].max():.3e}") if len(flips) else None,
+                      "reference_frames_with_margin_under_1e-2": int((margin < 1e-2).sum()),
+                      "prob_err_max": float(f"{np.abs(pr - ref).max():.3e}"),
+                      "cls_f16_rel_err_max": float(f"{rel.max():.3e}")}
     return out
 
 
