@@ -9,6 +9,7 @@
 // right-hand context (seq_len/2 rows) has been encoded by batches the session's stream is already ordered
 // after, in groups of `classify_every` frames, so the head never drains the encoder lanes mid-clip.
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <thread>
 
@@ -247,10 +248,13 @@ int finish_impl(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const 
     }
     if (f->stream_host) {                                               // rows have been leaving all along: the rest
         // (a consumer that fell NT tickets behind makes queue_row_copy skip: wait for it, the clip is over anyway)
-        while (f->copied < f->encoded) {
+        for (int spins = 0; f->copied < f->encoded; ++spins) {
             rc = queue_row_copy(f, f->encoded);
             if (rc) return rc;
-            if (f->copied < f->encoded) std::this_thread::yield();
+            if (f->copied < f->encoded) {
+                if (spins > 20000) return cbas_fail(CBAS_ESTATE, "cbas_fused_finish: the consumer of cbas_fused_rows_ready has stalled");
+                std::this_thread::sleep_for(std::chrono::microseconds(500));      // at most ~10 s
+            }
         }
     } else if (cls_f16_host)
         HIP_TRY(hipMemcpyAsync(cls_f16_host, f->cls16, (size_t)f->encoded * f->D * 2, hipMemcpyDeviceToHost, f->st));

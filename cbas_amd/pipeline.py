@@ -873,6 +873,8 @@ class ClipRunner:
                         ent[0].stream_rows_to(video_len)
                         pump = _RowsPump(ent[0], rows_sink)
                 try:
+                    if pump is not None and pump.error is not None:      # the file cannot be written: stop encoding for it
+                        raise pump.error
                     ent[0].push_host(frames, channel=1)                  # green channel, cbas.py:431
                 except BaseException:
                     if pump is not None:
@@ -937,6 +939,10 @@ class _RowsPump:
                     time.sleep(0.0005)
         except BaseException as e:  # noqa: BLE001 - re-raised by finish()
             self._err = e
+
+    @property
+    def error(self):
+        return self._err
 
     def finish(self, total: int) -> None:
         self._total = int(total)
