@@ -244,16 +244,44 @@ def synth_head_weights(cfg: HeadConfig, seed: int = 4321) -> Dict[str, np.ndarra
 # Checkpoint readers (no transformers / torch.nn dependency)
 # ----------------------------------------------------------------------------------------------
 
+def _load_safetensors_f32(path: str) -> Dict[str, np.ndarray]:
+    """One safetensors file as float32 arrays.  numpy has no bfloat16: files holding bf16 (or other torch-only) tensors
+    go through torch."""
+    try:
+        from safetensors.numpy import load_file
+        raw = load_file(path)
+        return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in raw.items()}
+    except (TypeError, ValueError, KeyError):
+        from safetensors.torch import load_file as load_torch
+        return {k: np.ascontiguousarray(v.float().numpy()) for k, v in load_torch(path).items()}
+
+
 def load_encoder_checkpoint(ckpt_dir: str) -> Tuple[ViTConfig, Dict[str, np.ndarray]]:
     """Read ``config.json`` + ``model.safetensors`` written by ``save_pretrained`` / the HF hub."""
     cfg = ViTConfig.from_json_file(os.path.join(ckpt_dir, "config.json"))
     st_path = os.path.join(ckpt_dir, "model.safetensors")
-    if not os.path.exists(st_path):
-        raise FileNotFoundError(f"{st_path} not found (sharded / .bin checkpoints are not supported)")
-    from safetensors.numpy import load_file
-    raw = load_file(st_path)
-    weights = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in raw.items()}
-    missing = [k for k in encoder_param_shapes(cfg) if k not in weights and not k.endswith("mask_token")]
+    index = os.path.join(ckpt_dir, "model.safetensors.index.json")
+    if os.path.exists(st_path):
+        shards = [st_path]
+    elif os.path.exists(index):                                 # a sharded save_pretrained (max_shard_size)
+        import json
+        with open(index) as f:
+            shards = sorted({os.path.join(ckpt_dir, v) for v in json.load(f)["weight_map"].values()})
+    else:
+        raise FileNotFoundError(f"{st_path} not found (.bin checkpoints are not supported: convert with save_pretrained)")
+    weights = {}
+    for shard in shards:
+        weights.update(_load_safetensors_f32(shard))
+    needed = [k for k in encoder_param_shapes(cfg) if not k.endswith("mask_token")]
+    missing = [k for k in needed if k not in weights]
+    if missing:
+        # a checkpoint saved from a task model keeps its backbone under a prefix ("dinov3_vit.", "backbone.", ...):
+        # from_pretrained strips it (base_model_prefix), so does this
+        for pre in sorted({k.split(".", 1)[0] + "." for k in weights if "." in k}):
+            sub = {k[len(pre):]: v for k, v in weights.items() if k.startswith(pre)}
+            if all(k in sub for k in needed):
+                weights, missing = sub, []
+                break
     if missing:
         raise KeyError(f"checkpoint {ckpt_dir} lacks tensors: {missing[:4]}{'...' if len(missing) > 4 else ''}")
     return cfg, weights

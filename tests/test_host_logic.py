@@ -252,3 +252,50 @@ def test_fp8_rows_are_stamped_as_such(tmp_path):
     # a project on the fp16 encoder re-encodes such a file; an fp8 run finds it up to date
     assert _needs_encoding(v8, "facebook/dinov3-vitb16-pretrain-lvd1689m")
     assert not _needs_encoding(v8, "facebook/dinov3-vitb16-pretrain-lvd1689m#mx-fp8")
+
+
+def test_checkpoint_loader_reads_bf16_and_sharded_saves(tmp_path):
+    """A checkpoint someone re-saved in bfloat16 (numpy cannot hold it) or in shards (`max_shard_size`) loads as float32."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    cfg = Cfg.VIT_TINY
+    w = W.synth_encoder_weights(cfg, 1234)
+    plain = str(tmp_path / "plain")
+    W.save_encoder_checkpoint(plain, cfg, w)
+    _, ref = W.load_encoder_checkpoint(plain)
+    assert all(np.array_equal(ref[k], np.asarray(w[k], np.float32)) for k in w)
+    b16 = tmp_path / "bf16"
+    b16.mkdir()
+    (b16 / "config.json").write_text(open(os.path.join(plain, "config.json")).read())
+    save_file({k: torch.from_numpy(np.asarray(v, np.float32)).to(torch.bfloat16).contiguous() for k, v in w.items()},
+              str(b16 / "model.safetensors"))
+    _, got = W.load_encoder_checkpoint(str(b16))
+    for k, v in w.items():
+        want = torch.from_numpy(np.asarray(v, np.float32)).to(torch.bfloat16).float().numpy()
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], want), k
+    sh = tmp_path / "sharded"
+    sh.mkdir()
+    (sh / "config.json").write_text(open(os.path.join(plain, "config.json")).read())
+    names = sorted(w)
+    parts = [names[0::2], names[1::2]]
+    wm = {}
+    for i, part in enumerate(parts):
+        fn = f"model-0000{i + 1}-of-00002.safetensors"
+        save_file({k: torch.from_numpy(np.ascontiguousarray(np.asarray(w[k], np.float32))) for k in part}, str(sh / fn))
+        wm.update({k: fn for k in part})
+    (sh / "model.safetensors.index.json").write_text(json.dumps({"metadata": {}, "weight_map": wm}))
+    _, got = W.load_encoder_checkpoint(str(sh))
+    assert all(np.array_equal(got[k], ref[k]) for k in ref)
+    with pytest.raises(FileNotFoundError):
+        W.load_encoder_checkpoint(str(tmp_path))
+    # a backbone saved under a task model's prefix
+    pre = tmp_path / "prefixed"
+    pre.mkdir()
+    (pre / "config.json").write_text(open(os.path.join(plain, "config.json")).read())
+    tensors = {"dinov3_vit." + k: torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32))) for k, v in w.items()}
+    tensors["classifier.weight"] = torch.zeros(3, cfg.hidden_size)
+    save_file(tensors, str(pre / "model.safetensors"))
+    _, got = W.load_encoder_checkpoint(str(pre))
+    assert all(np.array_equal(got[k], ref[k]) for k in ref)
+
