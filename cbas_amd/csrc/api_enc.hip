@@ -41,6 +41,8 @@ struct LayerW {
     // those rounded weights and the folded biases beta W^T + b
     f16 *wqkv_f = nullptr, *wup_f = nullptr;
     float *qkv_cs = nullptr, *qkv_bf = nullptr, *up_cs = nullptr, *up_bf = nullptr;
+    // precision 3: the fp32 weights themselves ([N][K] as stored in the blob; q | k | v packed into one [3D][D] copy)
+    const float *wqkv32 = nullptr, *wo32 = nullptr, *wup32 = nullptr, *wdown32 = nullptr;
 };
 
 struct Slot {
@@ -71,6 +73,8 @@ struct cbas_enc {
     uint32_t* w8_sc = nullptr;                 //              and their block scales
     uint32_t *sc_h = nullptr, *sc_u = nullptr; // precision 2: block scales of the fp8 activations in h16 / u16 ([K/128][rows_cap])
     f16 *wpatch, *wpatch2, *wpatch_lo, *wpatch2_lo;
+    float* w32 = nullptr;                      // precision 3: packed q|k|v weights of every layer + the (D,256) patch weight
+    const float* wpatch32 = nullptr;
     float* qkv_bias_all = nullptr;
     float* prefix_dev = nullptr;        // (1+R, D): cls (+ its position embedding for DINOv2) | registers
     float* pos_tab = nullptr;           // DINOv2: (Pmax, D) position embedding interpolated to the current grid
@@ -377,9 +381,102 @@ int run_last_layer_cls(cbas_enc* h, const LayerW& w, int n, int T, hipStream_t s
     return CBAS_OK;
 }
 
+// precision 3: the same schedule with every buffer and every contraction in fp32 (vit_f32.hip).  The workspace pointers
+// (A_patch, h16, qkv16, u16, cls16) are allocated at 4 bytes per element in this mode and hold floats.
+int run_blocks_f32(cbas_enc* h, int n, int height, int width, float* cls_f32, f16* cls_f16, hipStream_t st,
+                   int stop_layer, int stop_stage) {
+    const int ps = h->cfg.patch_size;
+    const int nh = height / ps, nw = width / ps, P = nh * nw, T = P + h->NP;
+    const int D = h->D, F = h->F;
+    const int M = n * T;
+    h->last_rows = M;
+    int rc = ensure_rope(h, nh, nw);
+    if (rc) return rc;
+    float* const A32 = reinterpret_cast<float*>(h->A_patch);
+    float* const h32 = reinterpret_cast<float*>(h->h16);
+    float* const qkv32 = reinterpret_cast<float*>(h->qkv16);
+    float* const u32 = reinterpret_cast<float*>(h->u16);
+    const float eps = h->cfg.layer_norm_eps;
+
+    Gemm32VitParams g{};
+    g.A = A32; g.lda = 256; g.W = h->wpatch32; g.M = n * P; g.N = D; g.K = 256; g.bias = h->patch_b; g.out = h->x; g.ldo = D;
+    g.patches_per_frame = P; g.tokens_per_frame = T; g.n_prefix = h->NP; g.pos = h->cfg.use_rope ? nullptr : h->pos_tab;
+    { PROF(CBAS_PROF_PATCH, 2.0 * g.M * g.N * g.K); LAUNCH_TRY(launch_gemm_f32_vit(EPI_PATCH, g, st)); }
+    if (stop_layer == 0 && stop_stage == 0) return CBAS_OK;
+
+    const bool prune = h->prune_last && stop_layer < 0 && (cls_f32 || cls_f16);
+    auto qkv_params = [&](const LayerW& w, Gemm32VitParams& q) {
+        q.K = D; q.D = D; q.tokens_per_frame = T; q.n_prefix = h->NP;
+        if (h->cfg.use_rope) { q.rope_cos = h->rope_cos; q.rope_sin = h->rope_sin; }
+    };
+    for (int l = 0; l < h->L; ++l) {
+        const LayerW& w = h->layers[l];
+        auto stop = [&](int stage) { return stop_layer == l && stop_stage == stage; };
+        if (prune && l == h->L - 1) {
+            // the last layer feeds only the final norm of the CLS rows (see run_last_layer_cls): K | V for every row,
+            // everything else for the n CLS rows, read and written in place with a row stride of T*D
+            const int64_t cap = round_up(h->cfg.max_batch, 128);
+            float* qc = reinterpret_cast<float*>(h->cls16);      // [n][D] CLS queries
+            float* cc = qc + cap * D;                            // [n][D] attention context
+            float* hc = cc + cap * D;                            // [n][D] LayerNorm rows
+            float* uc = hc + cap * D;                            // [n][F] GELU(up_proj)
+            { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln1_w, w.ln1_b, h32, M, D, eps, st)); }
+            Gemm32VitParams kv{};
+            qkv_params(w, kv);
+            kv.A = h32; kv.lda = D; kv.W = w.wqkv32 + (size_t)D * D; kv.M = M; kv.N = 2 * D; kv.bias = w.qkv_b + D;
+            kv.out = qkv32 + D; kv.ldo = 3 * D; kv.sec0 = 1;
+            { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_QKV, kv, st)); }
+            Gemm32VitParams q{};
+            qkv_params(w, q);
+            q.A = h32; q.lda = (int64_t)T * D; q.W = w.wqkv32; q.M = n; q.N = D; q.bias = w.qkv_b; q.out = qc; q.ldo = D;
+            q.tokens_per_frame = 1; q.n_prefix = 1; q.sec0 = 0;       // every row is token 0: no RoPE
+            { PROF(CBAS_PROF_QKV, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_QKV, q, st)); }
+            { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * D); LAUNCH_TRY(launch_attention_f32(qkv32, qc, cc, n, T, D, h->NH, st)); }
+            Gemm32VitParams o{};
+            o.A = cc; o.lda = D; o.W = w.wo32; o.M = n; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out = h->x; o.ldo = (int64_t)T * D;
+            { PROF(CBAS_PROF_OPROJ, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, o, st)); }
+            { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, (int64_t)T * D, w.ln2_w, w.ln2_b, hc, n, D, eps, st)); }
+            Gemm32VitParams u{};
+            u.A = hc; u.lda = D; u.W = w.wup32; u.M = n; u.N = F; u.K = D; u.bias = w.up_b; u.out = uc; u.ldo = F;
+            { PROF(CBAS_PROF_UP, 2.0 * n * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_GELU, u, st)); }
+            Gemm32VitParams d{};
+            d.A = uc; d.lda = F; d.W = w.wdown32; d.M = n; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out = h->x; d.ldo = (int64_t)T * D;
+            { PROF(CBAS_PROF_DOWN, 2.0 * n * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, d, st)); }
+            break;
+        }
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln1_w, w.ln1_b, h32, M, D, eps, st)); }
+        if (stop(1)) return CBAS_OK;
+        Gemm32VitParams q{};
+        qkv_params(w, q);
+        q.A = h32; q.lda = D; q.W = w.wqkv32; q.M = M; q.N = 3 * D; q.bias = w.qkv_b; q.out = qkv32; q.ldo = 3 * D;
+        { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_QKV, q, st)); }
+        if (stop(2)) return CBAS_OK;
+        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention_f32(qkv32, nullptr, h32, n, T, D, h->NH, st)); }
+        if (stop(3)) return CBAS_OK;
+        Gemm32VitParams o{};
+        o.A = h32; o.lda = D; o.W = w.wo32; o.M = M; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out = h->x; o.ldo = D;
+        { PROF(CBAS_PROF_OPROJ, 2.0 * M * (double)D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, o, st)); }
+        if (stop(4)) return CBAS_OK;
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln2_w, w.ln2_b, h32, M, D, eps, st)); }
+        if (stop(5)) return CBAS_OK;
+        Gemm32VitParams u{};
+        u.A = h32; u.lda = D; u.W = w.wup32; u.M = M; u.N = F; u.K = D; u.bias = w.up_b; u.out = u32; u.ldo = F;
+        { PROF(CBAS_PROF_UP, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_GELU, u, st)); }
+        if (stop(6)) return CBAS_OK;
+        Gemm32VitParams d{};
+        d.A = u32; d.lda = F; d.W = w.wdown32; d.M = M; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out = h->x; d.ldo = D;
+        { PROF(CBAS_PROF_DOWN, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, d, st)); }
+        if (stop(7)) return CBAS_OK;
+    }
+    if (cls_f32 || cls_f16)
+        LAUNCH_TRY(launch_final_norm_cls(h->x, h->norm_w, h->norm_b, cls_f32, cls_f16, n, T, D, eps, st));
+    return CBAS_OK;
+}
+
 // Everything after ingest: patch GEMM, L transformer blocks, final CLS norm.
 int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_scale, float* cls_f32,
                f16* cls_f16, hipStream_t st, int stop_layer, int stop_stage) {
+    if (h->cfg.precision == 3) return run_blocks_f32(h, n, height, width, cls_f32, cls_f16, st, stop_layer, stop_stage);
     const int ps = h->cfg.patch_size;
     const int nh = height / ps, nw = width / ps, P = nh * nw, T = P + h->NP;
     const int D = h->D, F = h->F;
@@ -513,8 +610,12 @@ int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, in
                    int stop_layer, int stop_stage) {
     const int ps = h->cfg.patch_size;
     const int T = (height / ps) * (width / ps) + h->NP;
-    LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
-                                h->x, h->prefix, h->NP, h->D, T, ps, st));
+    if (h->cfg.precision == 3)
+        LAUNCH_TRY(launch_im2col_u8_f32(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride,
+                                        reinterpret_cast<float*>(h->A_patch), h->x, h->prefix, h->NP, h->D, T, ps, st));
+    else
+        LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
+                                    h->x, h->prefix, h->NP, h->D, T, ps, st));
     return run_blocks(h, n, height, width, 256, 1.0f / 255.0f, cls_f32, cls_f16, st, stop_layer, stop_stage);
 }
 
@@ -570,7 +671,7 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
     for (auto& t : h->pos_tables) { if (t.cos) (void)hipFree(t.cos); if (t.sin) (void)hipFree(t.sin); if (t.fac) (void)hipFree(t.fac); if (t.pos) (void)hipFree(t.pos); }
     void* bufs[] = {h->blob, h->w16, h->w16_lo, h->qkv_bias_all, h->prefix_dev,
                     h->A_patch, h->h16, h->qkv16, h->u16, h->x, h->cls16, h->w8, h->w8_sc, h->sc_h, h->sc_u,
-                    h->w16_fold, h->fold_vec, h->x16, h->lnst};
+                    h->w16_fold, h->fold_vec, h->x16, h->lnst, h->w32};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->compute) (void)hipStreamDestroy(h->compute);
@@ -590,7 +691,8 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         return cbas_fail(CBAS_EINVAL, "intermediate_size=%d must be a multiple of 128", c.intermediate_size);
     if (c.hidden_size > 1024) return cbas_fail(CBAS_EINVAL, "hidden_size > 1024 not supported");
     if (c.patch_size != 16 && c.patch_size != 14) return cbas_fail(CBAS_EINVAL, "patch_size must be 14 or 16");
-    if (c.precision < 0 || c.precision > 2) return cbas_fail(CBAS_EINVAL, "precision=%d: 0 (fp16), 1 (fp16 hi+lo weights) or 2 (MX-fp8)", c.precision);
+    if (c.precision < 0 || c.precision > 3)
+        return cbas_fail(CBAS_EINVAL, "precision=%d: 0 (fp16), 1 (fp16 hi+lo weights), 2 (MX-fp8) or 3 (fp32, the reference's CPU arithmetic)", c.precision);
     if (c.precision == 2 && (c.hidden_size % 256 || c.intermediate_size % 256))
         return cbas_fail(CBAS_EINVAL, "precision 2 (MX-fp8) needs hidden_size and intermediate_size to be multiples of 256 "
                                       "(K-tiles of 128 consumed in pairs); got %d / %d", c.hidden_size, c.intermediate_size);
@@ -627,8 +729,14 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
 
     // fp16 weight arena: patch (D*256 + D*512) + per layer (3DD + DD + FD + DF)
     const int64_t n16 = D * 256 + D * 512 + (int64_t)h->L * (4 * D * D + 2 * F * D);
-    CREATE_TRY(hipMalloc(&h->w16, n16 * sizeof(f16)));
+    const bool p3 = c.precision == 3;         // fp32 end to end: no fp16 copies, every workspace 4 bytes per element
+    if (!p3) CREATE_TRY(hipMalloc(&h->w16, n16 * sizeof(f16)));
     if (c.precision == 1) CREATE_TRY(hipMalloc(&h->w16_lo, n16 * sizeof(f16)));
+    float* w32p = nullptr;
+    if (p3) {
+        CREATE_TRY(hipMalloc(&h->w32, (D * 256 + (int64_t)h->L * 3 * D * D) * sizeof(float)));
+        w32p = h->w32;
+    }
     uint8_t* w8p = nullptr;
     uint32_t* s8p = nullptr;
     if (c.precision == 2) {
@@ -675,7 +783,14 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     h->wpatch = w; w += D * 256;
     h->wpatch2 = w; w += D * 512;
     h->wpatch_lo = lo(h->wpatch); h->wpatch2_lo = lo(h->wpatch2);
-    int rc = launch_pack_patch_weight(patch_w, h->wpatch, h->wpatch_lo, h->wpatch2, h->wpatch2_lo, (int)D, c.patch_size, st);
+    int rc = 0;
+    if (p3) {
+        h->wpatch32 = w32p;
+        rc = launch_pack_patch_weight_f32(patch_w, w32p, (int)D, c.patch_size, st);
+        w32p += D * 256;
+    } else {
+        rc = launch_pack_patch_weight(patch_w, h->wpatch, h->wpatch_lo, h->wpatch2, h->wpatch2_lo, (int)D, c.patch_size, st);
+    }
 
     h->layers.resize(h->L);
     for (int l = 0; l < h->L && !rc; ++l) {
@@ -704,12 +819,21 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         lw.wup = w; w += F * D;
         lw.wdown = w; w += D * F;
         lw.wqkv_lo = lo(lw.wqkv); lw.wo_lo = lo(lw.wo); lw.wup_lo = lo(lw.wup); lw.wdown_lo = lo(lw.wdown);
-        rc |= launch_convert_f16(qw, lw.wqkv, lw.wqkv_lo, D * D, st);
-        rc |= launch_convert_f16(kw, lw.wqkv + D * D, lw.wqkv_lo ? lw.wqkv_lo + D * D : nullptr, D * D, st);
-        rc |= launch_convert_f16(vw, lw.wqkv + 2 * D * D, lw.wqkv_lo ? lw.wqkv_lo + 2 * D * D : nullptr, D * D, st);
-        rc |= launch_convert_f16(ow, lw.wo, lw.wo_lo, D * D, st);
-        rc |= launch_convert_f16(uw, lw.wup, lw.wup_lo, F * D, st);
-        rc |= launch_convert_f16(dw, lw.wdown, lw.wdown_lo, D * F, st);
+        if (p3) {
+            // q, k, v sit in the blob with their biases between them: one packed [3D][D] copy; the rest is used in place
+            CREATE_TRY(hipMemcpyAsync(w32p, qw, D * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CREATE_TRY(hipMemcpyAsync(w32p + D * D, kw, D * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CREATE_TRY(hipMemcpyAsync(w32p + 2 * D * D, vw, D * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+            lw.wqkv32 = w32p; w32p += 3 * D * D;
+            lw.wo32 = ow; lw.wup32 = uw; lw.wdown32 = dw;
+        } else {
+            rc |= launch_convert_f16(qw, lw.wqkv, lw.wqkv_lo, D * D, st);
+            rc |= launch_convert_f16(kw, lw.wqkv + D * D, lw.wqkv_lo ? lw.wqkv_lo + D * D : nullptr, D * D, st);
+            rc |= launch_convert_f16(vw, lw.wqkv + 2 * D * D, lw.wqkv_lo ? lw.wqkv_lo + 2 * D * D : nullptr, D * D, st);
+            rc |= launch_convert_f16(ow, lw.wo, lw.wo_lo, D * D, st);
+            rc |= launch_convert_f16(uw, lw.wup, lw.wup_lo, F * D, st);
+            rc |= launch_convert_f16(dw, lw.wdown, lw.wdown_lo, D * F, st);
+        }
         if (c.precision == 2) {
             lw.wqkv8 = w8p; w8p += 3 * D * D;  lw.sqkv = s8p; s8p += 3 * D * D / 128;
             lw.wo8 = w8p; w8p += D * D;        lw.so = s8p; s8p += D * D / 128;
@@ -754,11 +878,12 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     h->prow_cap = round_up((int64_t)c.max_batch * Pmax, 128);
     h->rope_cap = (int)Pmax;
     h->pos_tables.reserve(cbas_enc::POS_TABLES_MAX);     // entries are handed out by pointer: never reallocate
+    const size_t esz = p3 ? sizeof(float) : sizeof(f16);      // activation element size (A_patch is 512 f16 = 256 f32 per row)
     CREATE_TRY(hipMalloc(&h->A_patch, h->prow_cap * 512 * sizeof(f16)));
     CREATE_TRY(hipMalloc(&h->x, h->rows_cap * D * sizeof(float)));
-    CREATE_TRY(hipMalloc(&h->h16, h->rows_cap * D * sizeof(f16)));
-    CREATE_TRY(hipMalloc(&h->qkv16, h->rows_cap * 3 * D * sizeof(f16)));
-    CREATE_TRY(hipMalloc(&h->u16, h->rows_cap * F * sizeof(f16)));
+    CREATE_TRY(hipMalloc(&h->h16, h->rows_cap * D * esz));
+    CREATE_TRY(hipMalloc(&h->qkv16, h->rows_cap * 3 * D * esz));
+    CREATE_TRY(hipMalloc(&h->u16, h->rows_cap * F * esz));
     const int64_t sch_elems = (D / 128) * h->rows_cap, scu_elems = (F / 128) * h->rows_cap;    // dwords
     if (c.precision == 2) {
         CREATE_TRY(hipMalloc(&h->sc_h, sch_elems * 4));
@@ -773,13 +898,13 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         CREATE_TRY(hipMemsetAsync(h->lnst, 0, 4 * h->rows_cap * sizeof(float2), st));
     }
     const int64_t cls_elems = round_up(c.max_batch, 128) * (3 * D + F);
-    CREATE_TRY(hipMalloc(&h->cls16, cls_elems * sizeof(f16)));
-    CREATE_TRY(hipMemsetAsync(h->cls16, 0, cls_elems * sizeof(f16), st));
+    CREATE_TRY(hipMalloc(&h->cls16, cls_elems * esz));
+    CREATE_TRY(hipMemsetAsync(h->cls16, 0, cls_elems * esz, st));
     CREATE_TRY(hipMemsetAsync(h->A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
     CREATE_TRY(hipMemsetAsync(h->x, 0, h->rows_cap * D * sizeof(float), st));
-    CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * sizeof(f16), st));
-    CREATE_TRY(hipMemsetAsync(h->qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
-    CREATE_TRY(hipMemsetAsync(h->u16, 0, h->rows_cap * F * sizeof(f16), st));
+    CREATE_TRY(hipMemsetAsync(h->h16, 0, h->rows_cap * D * esz, st));
+    CREATE_TRY(hipMemsetAsync(h->qkv16, 0, h->rows_cap * 3 * D * esz, st));
+    CREATE_TRY(hipMemsetAsync(h->u16, 0, h->rows_cap * F * esz, st));
     // second compute lane (see cbas_enc::Lane); CBAS_LANES=1 (read here, once per handle) keeps a single lane
     {
         const char* e = getenv("CBAS_LANES");
@@ -791,9 +916,9 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
             cbas_enc::Lane& L1 = h->lanes[1];
             CREATE_TRY(hipMalloc(&L1.A_patch, h->prow_cap * 512 * sizeof(f16)));
             CREATE_TRY(hipMalloc(&L1.x, h->rows_cap * D * sizeof(float)));
-            CREATE_TRY(hipMalloc(&L1.h16, h->rows_cap * D * sizeof(f16)));
-            CREATE_TRY(hipMalloc(&L1.qkv16, h->rows_cap * 3 * D * sizeof(f16)));
-            CREATE_TRY(hipMalloc(&L1.u16, h->rows_cap * F * sizeof(f16)));
+            CREATE_TRY(hipMalloc(&L1.h16, h->rows_cap * D * esz));
+            CREATE_TRY(hipMalloc(&L1.qkv16, h->rows_cap * 3 * D * esz));
+            CREATE_TRY(hipMalloc(&L1.u16, h->rows_cap * F * esz));
             if (c.precision == 2) {
                 CREATE_TRY(hipMalloc(&L1.sc_h, sch_elems * 4));
                 CREATE_TRY(hipMalloc(&L1.sc_u, scu_elems * 4));
@@ -806,13 +931,13 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
                 CREATE_TRY(hipMemsetAsync(L1.x16, 0, h->rows_cap * D * sizeof(f16), st));
                 CREATE_TRY(hipMemsetAsync(L1.lnst, 0, 4 * h->rows_cap * sizeof(float2), st));
             }
-            CREATE_TRY(hipMalloc(&L1.cls16, cls_elems * sizeof(f16)));
-            CREATE_TRY(hipMemsetAsync(L1.cls16, 0, cls_elems * sizeof(f16), st));
+            CREATE_TRY(hipMalloc(&L1.cls16, cls_elems * esz));
+            CREATE_TRY(hipMemsetAsync(L1.cls16, 0, cls_elems * esz, st));
             CREATE_TRY(hipMemsetAsync(L1.A_patch, 0, h->prow_cap * 512 * sizeof(f16), st));
             CREATE_TRY(hipMemsetAsync(L1.x, 0, h->rows_cap * D * sizeof(float), st));
-            CREATE_TRY(hipMemsetAsync(L1.h16, 0, h->rows_cap * D * sizeof(f16), st));
-            CREATE_TRY(hipMemsetAsync(L1.qkv16, 0, h->rows_cap * 3 * D * sizeof(f16), st));
-            CREATE_TRY(hipMemsetAsync(L1.u16, 0, h->rows_cap * F * sizeof(f16), st));
+            CREATE_TRY(hipMemsetAsync(L1.h16, 0, h->rows_cap * D * esz, st));
+            CREATE_TRY(hipMemsetAsync(L1.qkv16, 0, h->rows_cap * 3 * D * esz, st));
+            CREATE_TRY(hipMemsetAsync(L1.u16, 0, h->rows_cap * F * esz, st));
             CREATE_TRY(hipStreamCreateWithFlags(&L1.stream, hipStreamNonBlocking));
         }
         CREATE_TRY(hipEventCreateWithFlags(&h->lane0_async_done, hipEventDisableTiming));
@@ -884,7 +1009,10 @@ extern "C" int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int 
     const int T = (height / ps) * (width / ps) + h->NP;
     rc = sync_enter(h, st);
     if (rc) return rc;
-    LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, ps, st));
+    if (h->cfg.precision == 3)
+        LAUNCH_TRY(launch_im2col_f32_f32(x_dev, n, height, width, reinterpret_cast<float*>(h->A_patch), h->x, h->prefix, h->NP, h->D, T, ps, st));
+    else
+        LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, ps, st));
     rc = run_blocks(h, n, height, width, 512, 1.0f, cls_f32_dev, (f16*)cls_f16_dev, st, -1, -1);
     if (rc) return rc;
     return sync_leave(h, st);
@@ -907,9 +1035,10 @@ extern "C" int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64
     int64_t cap = 0;
     switch (which) {
         case 0: src = h->x; cap = h->rows_cap * h->D * 4; break;
-        case 1: src = h->h16; cap = h->rows_cap * h->D * 2; break;
-        case 2: src = h->qkv16; cap = h->rows_cap * 3 * h->D * 2; break;
-        case 3: src = h->u16; cap = h->rows_cap * h->F * 2; break;
+        // precision 3 keeps these as fp32 (4 bytes per element)
+        case 1: src = h->h16; cap = h->rows_cap * h->D * (h->cfg.precision == 3 ? 4 : 2); break;
+        case 2: src = h->qkv16; cap = h->rows_cap * 3 * h->D * (h->cfg.precision == 3 ? 4 : 2); break;
+        case 3: src = h->u16; cap = h->rows_cap * h->F * (h->cfg.precision == 3 ? 4 : 2); break;
         default: return cbas_fail(CBAS_EINVAL, "unknown buffer %d", which);
     }
     if (n_bytes < 0 || n_bytes > cap) return cbas_fail(CBAS_EINVAL, "read of %lld bytes exceeds buffer (%lld)", (long long)n_bytes, (long long)cap);

@@ -13,36 +13,11 @@
 // projection of SURVEY.md §8(a) H1), :83-87 (lin0 + GELU), :96 (lin1) and the input half of
 // nn.LSTM :100 (W_ih x + b_ih + b_hh for both directions as one GEMM).
 #include "kernels.h"
+#include "gemm_f32_tile.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKF = 32;      // BKF floats = 128 bytes per LDS row
-constexpr int TILE_BYTES = BM * 128;
-
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (orig >> 3);
-}
-
-__device__ __forceinline__ void stage_tile32(const float* __restrict__ g, int64_t ld, int64_t row0, int64_t max_row,
-                                             int k0, char* lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
-        const int r = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        int64_t row = row0 + r;
-        row = row < max_row ? row : max_row;          // clamp: rows past the end are never stored
-        const float* src = g + row * ld + k0 + chunk * 4;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ f32x4 read_frag32(const char* lds_tile, int row, int chunk) {
-    const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-    return *reinterpret_cast<const f32x4*>(lds_tile + off);
-}
+using namespace f32tile;
 
 template <int GELU>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(Gemm32Params p) {

@@ -142,6 +142,44 @@ int launch_pack_fp8_weight(const float* src, uint8_t* w8, uint32_t* sc, int N, i
 int launch_pack_patch_weight(const float* w, f16* hi, f16* lo, f16* hi2, f16* lo2, int D, int ps, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
+// precision 3: the reference's fp32 CPU arithmetic (backend/cbas.py:433-434 autocast off on CPU; [tf]:523-548) on
+// v_mfma_f32_16x16x4_f32 - exact fp32 products and sums, k-ordered (vit_f32.hip).  Every buffer is fp32.
+// ---------------------------------------------------------------------------------------------
+struct Gemm32VitParams {
+    const float* A; int64_t lda;   // [M][lda], first K columns used (lda = T*D reads one row per frame: the CLS rows)
+    const float* W;                // [N][K], the HF Linear weight as stored
+    int M, N, K;                   // N % 128 == 0, K % 32 == 0
+    const float* bias;             // [N]
+    const float* lambda;           // [N]   (EPI_RESID)
+    float* out; int64_t ldo;       // EPI_PATCH / EPI_RESID: the residual stream x; EPI_QKV / EPI_GELU: qkv / u
+    // EPI_PATCH
+    int patches_per_frame, tokens_per_frame, n_prefix;
+    const float* pos;              // DINOv2 position embedding [P][N], or nullptr
+    // EPI_QKV
+    const float* rope_cos;         // [P][64], or nullptr: no RoPE
+    const float* rope_sin;
+    int D;                         // hidden size (q | k | v sections of width D)
+    int sec0;                      // section of output column 0
+};
+int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream);
+// uint8 pixels -> A[n*P][256] fp32 = float(double(pixel) / 255.0), the reference's cbas.py:431 value bit for bit
+// (+ prefix rows of x, as launch_im2col_u8)
+int launch_im2col_u8_f32(const uint8_t* frames, int n, int height, int width, int64_t frame_stride, int64_t row_stride,
+                         int64_t pixel_stride, float* A, float* x, const float* prefix_tokens, int n_prefix, int D, int T,
+                         int ps, hipStream_t stream);
+// float32 (n,H,W) -> A[n*P][256] fp32, values as they are
+int launch_im2col_f32_f32(const float* frames, int n, int height, int width, float* A, float* x,
+                          const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream);
+// patch weight (D,3,ps,ps) fp32 -> (D,256) fp32 in the 16x16 slot layout, summed over the 3 identical input channels in
+// double and rounded once
+int launch_pack_patch_weight_f32(const float* w, float* out, int D, int ps, hipStream_t stream);
+int launch_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int M, int D,
+                         float eps, hipStream_t stream);
+// qkv [n*T][3D] fp32 (q pre-scaled by 1/8, RoPE applied) -> out [n*T][D] fp32; q_cls as launch_attention
+int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n, int T, int D, int n_heads,
+                         hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
 // classifier head (all fp32)
 // ---------------------------------------------------------------------------------------------
 struct Gemm32Params {

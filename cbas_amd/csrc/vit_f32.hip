@@ -1,0 +1,487 @@
+// Precision 3: the encoder in the reference's own CPU arithmetic - fp32 operands, fp32 products, fp32 sums - on gfx950.
+//
+// The reference's parity target is its CPU path: autocast is disabled there (backend/cbas.py:433-434), so every
+// nn.Linear of [tf] modeling_dinov3_vit.py runs as an fp32 GEMM, attention as fp32 SDPA, LayerNorm / GELU / RoPE in
+// fp32.  The fp16-operand kernels meet the 1e-3 CLS bar but move probabilities by ~1e-2, which flips near-tie labels;
+// this file is the mode that does not: every contraction on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate, bit for
+// bit a k-ordered fmaf chain: MI355X_MICROARCH.md "Matrix cores"), every activation buffer fp32, and the element-wise
+// steps written with the reference's rounding points (no FMA contraction across what are separate torch ops).
+//
+//   gemm_f32_vit_kernel<EPI>   every nn.Linear of the ViT with its epilogue fused:
+//        EPI_PATCH  Conv2d k=s=16 as im2col GEMM + bias (+ DINOv2 position embedding), token scatter   [tf]:82-89
+//        EPI_QKV    + bias, RoPE on the patch rows of q and k ([tf]:238-268, rotate_half :203-207), q * 1/8 (exact)
+//        EPI_RESID  x += (acc + bias) * lambda                                        [tf]:342-343, :432-443
+//        EPI_GELU   exact-erf GELU(acc + bias)                                        [tf]:356
+//   attention_f32_kernel       softmax(q k^T) v per (frame, head), online softmax over 64-key blocks   [tf]:210-234
+//   layernorm_f32_kernel       [tf]:404,410
+//   im2col_*_f32, pack_patch_weight_f32   backend/cbas.py:431 (green / 255.0 in double, then float), :674
+//
+// The matrix pipe runs at 1/16 of the fp16 rate here (157 TFLOP/s peak), so the GEMM is MFMA-bound by a wide margin
+// and the geometry is the simple one of gemm_f32.hip: 128x128 tiles, 4 waves, two LDS buffers, LDS-DMA staging.
+#include "kernels.h"
+#include "gemm_f32_tile.h"
+
+namespace {
+
+using namespace f32tile;
+
+// a*c + b*s with every product and the sum rounded on its own, as the reference's `(q * cos) + (rotate_half(q) * sin)`
+__device__ __forceinline__ f32x4 rope_rot32(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
+#pragma clang fp contract(off)
+    const f32x4 t0 = a * c;
+    const f32x4 t1 = b * s;
+    return t0 + t1;
+}
+
+template <int EPI>
+__device__ __forceinline__ void vit32_epilogue_row(const Gemm32VitParams& p, int m, int head_col0, int lane,
+                                                   const f32x4 (&acc)[4]) {
+#pragma clang fp contract(off)
+    const int ncol = head_col0 + (lane >> 4) * 4;     // + j*16
+    if (EPI == EPI_PATCH) {
+        const int b = m / p.patches_per_frame;
+        const int pp = m - b * p.patches_per_frame;
+        const int64_t orow = (int64_t)b * p.tokens_per_frame + p.n_prefix + pp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            f32x4 v = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.pos) v = v + *reinterpret_cast<const f32x4*>(p.pos + (size_t)pp * p.N + n);
+            *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n) = v;
+        }
+    } else if (EPI == EPI_QKV) {
+        const int sec = head_col0 / p.D + p.sec0;      // 0 q, 1 k, 2 v: uniform over the 64-column group
+        const int t = m % p.tokens_per_frame;
+        const bool rope = p.rope_cos && (sec < 2) && (t >= p.n_prefix);
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + ncol + j * 16);
+        if (rope) {
+            const size_t ro = (size_t)(t - p.n_prefix) * 64 + (lane >> 4) * 4;
+            f32x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
+                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
+                // rotate_half(x)[d] = -x[d+32] (d < 32), x[d-32] (d >= 32)
+                o[j] = (j < 2) ? rope_rot32(v[j], c, -v[j + 2], s) : rope_rot32(v[j], c, v[j - 2], s);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = o[j];
+        }
+        const float qs = (sec == 0) ? 0.125f : 1.0f;   // head_dim^-0.5, an exact power of two: commutes with every rounding
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + ncol + j * 16) = v[j] * qs;
+    } else if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(p.lambda + n);
+            float* xp = p.out + (int64_t)m * p.ldo + n;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp);
+            const f32x4 hsc = (acc[j] + bv) * lv;       // layer_scale(linear(.)), rounded as its own op
+            *reinterpret_cast<f32x4*>(xp) = hsc + xv;   // + residual
+        }
+    } else {  // EPI_GELU
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            const f32x4 w = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + n);
+            *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = f32x4{gelu_erf(w[0]), gelu_erf(w[1]), gelu_erf(w[2]), gelu_erf(w[3])};
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_vit_kernel(Gemm32VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BUF_BYTES = 2 * TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tiles_n = p.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int col0 = tn * BN;
+    const int nk = p.K / BKF;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * BUF_BYTES;
+        stage_tile32(p.A, p.lda, row0, p.M - 1, kt * BKF, base, wave, lane);
+        stage_tile32(p.W, p.K, col0, p.N - 1, kt * BKF, base + TILE_BYTES, wave, lane);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* At = smem + cur * BUF_BYTES;
+        const char* Wt = At + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = read_frag32(At, wr * 64 + i * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = read_frag32(Wt, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = row0 + wr * 64 + i * 16 + (lane & 15);
+        if (m < p.M) vit32_epilogue_row<EPI>(p, (int)m, col0 + wc * 64, lane, acc[i]);
+    }
+}
+
+template <int EPI>
+int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
+    constexpr int lds = 4 * TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_vit_kernel<EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const int64_t grid = ((int64_t)(p.M + BM - 1) / BM) * (p.N / BN);
+    if (grid <= 0 || grid > 0x7fffffff) return -1;
+    hipLaunchKernelGGL((gemm_f32_vit_kernel<EPI>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ingest / weights / LayerNorm
+// ---------------------------------------------------------------------------------------------
+// One thread = one patch row of `ps` pixels; A[m][i*16 + j] with the 16x16 slot layout of im2col_u8_kernel (slots
+// with i >= ps or j >= ps stay zero: rows i >= ps are never written, the buffer is zeroed at allocation).
+template <typename SRC>
+__global__ void im2col_f32out_kernel(const SRC* __restrict__ frames, int n, int64_t frame_stride, int64_t row_stride,
+                                     int64_t pixel_stride, float* __restrict__ A, int nh, int nw, int ps) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n * nh * ps * nw;
+    if (gid >= total) return;
+    const int px = gid % nw;
+    const int64_t t1 = gid / nw;
+    const int y = t1 % (nh * ps);
+    const int b = t1 / (nh * ps);
+    const int py = y / ps, i = y - py * ps;
+    const SRC* src = frames + b * frame_stride + (int64_t)y * row_stride + (int64_t)px * ps * pixel_stride;
+    float* dst = A + ((int64_t)b * nh * nw + (int64_t)py * nw + px) * 256 + i * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = q * 4 + e;
+            float f = 0.f;
+            if (j < ps) {
+                if (sizeof(SRC) == 1) f = (float)((double)src[j * pixel_stride] / 255.0);     // numpy: uint8 / 255.0 -> float64; .float()
+                else f = (float)src[j * pixel_stride];
+            }
+            v[e] = f;
+        }
+        reinterpret_cast<f32x4*>(dst)[q] = v;
+    }
+}
+
+__global__ void write_prefix32_kernel(float* __restrict__ x, const float* __restrict__ prefix, int n, int n_prefix, int D, int T) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)n_prefix * (D / 4);
+    if (gid >= (int64_t)n * per) return;
+    const int b = gid / per;
+    const int rem = gid - (int64_t)b * per;
+    const int r = rem / (D / 4), c = rem - r * (D / 4);
+    reinterpret_cast<f32x4*>(x + ((int64_t)b * T + r) * D)[c] = reinterpret_cast<const f32x4*>(prefix + (int64_t)r * D)[c];
+}
+
+__global__ void pack_patch_weight_f32_kernel(const float* __restrict__ w, float* __restrict__ out, int D, int ps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over D*256
+    if (idx >= D * 256) return;
+    const int d = idx >> 8, k = idx & 255, i = k >> 4, j = k & 15;
+    float v = 0.f;
+    if (i < ps && j < ps) {
+        const float* base = w + (size_t)d * 3 * ps * ps + i * ps + j;
+        v = (float)(((double)base[0] + (double)base[ps * ps]) + (double)base[2 * ps * ps]);     // the 3 identical input channels
+    }
+    out[idx] = v;
+}
+
+// one wave per row, two-pass statistics in registers
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ out, int M, int D,
+                                                            float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int nvec = D >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        v[k] = (idx < nvec) ? reinterpret_cast<const f32x4*>(xr)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            const f32x4 d = v[k] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[idx];
+            const f32x4 bb = reinterpret_cast<const f32x4*>(beta)[idx];
+            reinterpret_cast<f32x4*>(out + (size_t)row * D)[idx] = (v[k] - mean) * rstd * g + bb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention, fp32.  One workgroup = `nwaves` 16-query tiles of one (frame, head); K and V stream through LDS in blocks
+// of 64 keys (two buffers, staged by 16-byte LDS-DMA with the swizzles applied on the source address).
+//   S^T = K Q^T   on v_mfma_f32_16x16x4_f32 with the key on the MFMA row: a lane holds, for ONE query (lane & 15), the
+//                 keys 16 kt + 4 (lane >> 4) + r - the softmax is in-lane plus two cross-lane steps, and those registers
+//                 ARE the B operand of the next product (k-slot (lane >> 4) of step (kt, r) <-> key 16 kt + 4 (lane >> 4) + r;
+//                 the A operand reads V with the same map, so the sum over keys is unchanged)
+//   O^T = V^T P^T one ds_read_b32 of V per MFMA
+// Online softmax over the key blocks (what torch's CPU flash kernel does too), everything fp32, expf from the device
+// library (accurate form).  K image: chunk c (16 B) of row r at position c ^ (r & 15) - ds_read_b128 of one chunk
+// column over 16 rows is conflict-free.  V image: chunk c of row r at c ^ (4 * ((r >> 2) & 1)) - the ds_read_b32 of 16
+// consecutive floats from rows 4g + r, g = 0..3, lands the two 16-lane halves of a 32-lane group on different banks.
+// ---------------------------------------------------------------------------------------------
+constexpr int AKB = 64;                     // keys per block
+constexpr int AIMG = AKB * 256;             // bytes of one K or V block image
+
+__global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
+                                                               float* __restrict__ out, int T, int D, int n_heads, int qblocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    const int pair = blockIdx.x / qblocks, qb = blockIdx.x - pair * qblocks;
+    const int b = pair / n_heads, hd = pair - b * n_heads;
+    const size_t ld = (size_t)3 * D;
+    const float* qbase = qkv + (size_t)b * T * ld + hd * 64;
+    const float* kbase = qbase + D;
+    const float* vbase = qbase + 2 * D;
+    const int g = lane >> 4, li = lane & 15;
+    const int nq = q_cls ? 1 : T;
+    const float* qsrc = q_cls ? q_cls + (size_t)b * D + hd * 64 : qbase;
+    const size_t qld = q_cls ? 0 : ld;
+    const int qt = qb * nwaves + wave;
+    const bool active = qt * 16 < nq;                      // wave-uniform
+    const int q = qt * 16 + li;
+    const int qrow = q < nq ? q : nq - 1;
+    f32x4 qf[4];                                           // Q[q][16c + 4g + e]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const f32x4*>(qsrc + (size_t)qrow * qld + 16 * c + 4 * g);
+
+    const int nkb = (T + AKB - 1) / AKB;
+    auto stage = [&](int buf, int kb) {
+        char* base = smem + buf * 2 * AIMG;
+        for (int p = wave; p < 32; p += nwaves) {          // 16 pieces (4 rows x 256 B) per image
+            const int img = p >> 4, piece = p & 15;
+            const int r = piece * 4 + g;
+            const int key = kb * AKB + r;
+            const int ks = key < T ? key : T - 1;          // rows past T re-read row T-1: finite, masked below
+            const int chunk = img ? (li ^ (((r >> 2) & 1) << 2)) : (li ^ (r & 15));
+            const float* src = (img ? vbase : kbase) + (size_t)ks * ld + chunk * 4;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + img * AIMG + piece * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float mrun = -INFINITY, lrun = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < nkb) stage(cur ^ 1, kb + 1);
+        if (active) {
+            const char* Ks = smem + cur * 2 * AIMG;
+            const char* Vs = Ks + AIMG;
+            f32x4 s[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + li) * 256 + (((4 * c + g) ^ li) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[c][e], acc, 0, 0, 0);
+                }
+                s[kt] = acc;
+            }
+            // s[kt][r] = S[q][key = kb*64 + kt*16 + 4g + r]   (q already carries the 1/8 scale)
+            float bm = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
+                    bm = fmaxf(bm, s[kt][r]);
+                }
+            bm = xor16_max(bm);
+            bm = xor32_max(bm);
+            const float mnew = fmaxf(mrun, bm);             // finite: every block holds at least one real key
+            const float alpha = expf(mrun - mnew);          // first block: exp(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = expf(s[kt][r] - mnew);
+                    psum += s[kt][r];
+                }
+            lrun = lrun * alpha + psum;                     // per-lane partial; the four g lanes are pooled at the end
+            mrun = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            const int vsw = (g & 1) << 2;                   // ((row >> 2) & 1) << 2 for row = 16 kt + 4g + r
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const char* vrow = Vs + (kt * 16 + 4 * g + r) * 256 + ((li & 3) << 2);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const float vf = *reinterpret_cast<const float*>(vrow + (((dt * 4 + (li >> 2)) ^ vsw) << 4));
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][r], o[dt], 0, 0, 0);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (!active) return;
+    lrun = xor16_add(lrun);
+    lrun = xor32_add(lrun);
+    if (q < nq) {
+        float* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = o[dt] / lrun;
+    }
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0 || p.N % BN || p.K % BKF || p.lda % 4 || p.ldo % 4) return -1;
+    if (epi == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;
+    switch (epi) {
+        case EPI_PATCH: return launch_vit32<EPI_PATCH>(p, stream);
+        case EPI_QKV:   return launch_vit32<EPI_QKV>(p, stream);
+        case EPI_RESID: return launch_vit32<EPI_RESID>(p, stream);
+        case EPI_GELU:  return launch_vit32<EPI_GELU>(p, stream);
+        default: return -1;
+    }
+}
+
+int launch_im2col_u8_f32(const uint8_t* frames, int n, int height, int width, int64_t frame_stride, int64_t row_stride,
+                         int64_t pixel_stride, float* A, float* x, const float* prefix_tokens, int n_prefix, int D, int T,
+                         int ps, hipStream_t stream) {
+    const int nh = height / ps, nw = width / ps;
+    const int64_t total = (int64_t)n * nh * ps * nw;
+    hipLaunchKernelGGL(im2col_f32out_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
+                       frame_stride, row_stride, pixel_stride, A, nh, nw, ps);
+    const int64_t tp = (int64_t)n * n_prefix * (D / 4);
+    hipLaunchKernelGGL(write_prefix32_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens, n,
+                       n_prefix, D, T);
+    return CHECK_LAUNCH();
+}
+
+int launch_im2col_f32_f32(const float* frames, int n, int height, int width, float* A, float* x,
+                          const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream) {
+    const int nh = height / ps, nw = width / ps;
+    const int64_t total = (int64_t)n * nh * ps * nw;
+    hipLaunchKernelGGL(im2col_f32out_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
+                       (int64_t)height * width, (int64_t)width, (int64_t)1, A, nh, nw, ps);
+    const int64_t tp = (int64_t)n * n_prefix * (D / 4);
+    hipLaunchKernelGGL(write_prefix32_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens, n,
+                       n_prefix, D, T);
+    return CHECK_LAUNCH();
+}
+
+int launch_pack_patch_weight_f32(const float* w, float* out, int D, int ps, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_patch_weight_f32_kernel, dim3((D * 256 + 255) / 256), dim3(256), 0, stream, w, out, D, ps);
+    return CHECK_LAUNCH();
+}
+
+int launch_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int M, int D,
+                         float eps, hipStream_t stream) {
+    const int nv = (D / 4 + 63) / 64;
+    const dim3 grid((M + 3) / 4), block(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_f32_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_f32_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 4: hipLaunchKernelGGL(layernorm_f32_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        default: return -1;
+    }
+    return CHECK_LAUNCH();
+}
+
+int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n, int T, int D, int n_heads,
+                         hipStream_t stream) {
+    if (n <= 0 || T <= 0 || D != n_heads * 64) return -1;
+    static bool attr_set = false;
+    constexpr int lds = 4 * AIMG;                           // two buffers x (K + V) = 64 KiB: two workgroups per CU
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    // waves per workgroup = query tiles per workgroup: the count in 5..8 that wastes the fewest tile slots (T = 201:
+    // 13 tiles -> 7 waves x 2 workgroups; T = 261: 17 -> 6 x 3; T = 1029: 65 -> 5 x 13), larger on ties
+    const int ntiles = q_cls ? 1 : (T + 15) / 16;
+    int nw = 8, best = 1 << 30;
+    for (int w = 8; w >= 5; --w) {
+        const int waste = (ntiles + w - 1) / w * w - ntiles;
+        if (waste < best) { best = waste; nw = w; }
+    }
+    if (q_cls) nw = 4;
+    const int qblocks = (ntiles + nw - 1) / nw;
+    const int64_t grid = (int64_t)n * n_heads * qblocks;
+    if (grid > 0x7fffffff) return -1;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks);
+    return CHECK_LAUNCH();
+}

@@ -119,7 +119,8 @@ class DinoEncoder:
 
     @property
     def precision(self) -> int:
-        """0 fp16 (default), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode (include/cbas_mi355x.h)."""
+        """0 fp16 (default), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode, 3 fp32 end to end - the reference's CPU
+        arithmetic, for label-exact runs (include/cbas_mi355x.h)."""
         return int(self._cfg_c.precision)
 
     # -- nn.Module-like surface used by the reference ------------------------------------------
@@ -292,8 +293,9 @@ class DinoEncoder:
                                                        stop_layer, stop_stage), "cbas_enc_debug_forward_u8")
         T = self.config.num_tokens(H, W)
         D, F = self.config.hidden_size, self.config.intermediate_size
-        shape, dt = {0: ((n * T, D), np.float32), 1: ((n * T, D), np.float16), 2: ((n * T, 3 * D), np.float16),
-                     3: ((n * T, F), np.float16)}[which]
+        act = np.float32 if self.precision == 3 else np.float16        # precision 3 keeps every activation buffer fp32
+        shape, dt = {0: ((n * T, D), np.float32), 1: ((n * T, D), act), 2: ((n * T, 3 * D), act),
+                     3: ((n * T, F), act)}[which]
         out = np.empty(shape, dt)
         _lib.check(self._lib.cbas_enc_debug_read(self._h, which, out.ctypes.data, out.nbytes), "cbas_enc_debug_read")
         return out

@@ -79,7 +79,14 @@ typedef struct cbas_enc_config {
                                         attention, GELU epilogue) - on v_mfma_scale_f32_16x16x128_f8f6f4; accumulation,
                                         residual stream, attention, patch embedding and the CLS tail of the last
                                         layer are unchanged.  CLS error is a few 1e-2: held to label parity only.
-                                        hidden_size and intermediate_size must be multiples of 256. */
+                                        hidden_size and intermediate_size must be multiples of 256.
+                                     3: fp32 end to end - the arithmetic of the reference's CPU path, which is the parity
+                                        target (backend/cbas.py:433-434: autocast off on CPU; [tf]:523-548): fp32
+                                        weights, activations, attention and LayerNorm, every contraction on
+                                        v_mfma_f32_16x16x4_f32 (exact fp32 products and sums), the element-wise steps
+                                        rounded where the reference's separate torch ops round.  CLS rows agree with
+                                        the reference to a few 1e-6, so the fp16 rows written to _cls.h5 and the argmax
+                                        labels are the reference's own.  ~1/7 of the default mode's frame rate. */
     int32_t use_rope;             /* 1: DINOv3 (RoPE on patch rows, no additive position embedding)     */
     int32_t pos_embed_grid;       /* G > 0: DINOv2-with-registers, learned (1+G*G, D) position embedding,
                                      bicubic-antialias interpolated to each frame's patch grid; else 0 */

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""How well-defined are the REFERENCE's own labels?  (build container only: imports /root/reference)
+
+The reference's fp32 CPU path is not one arithmetic: MKL / oneDNN choose their blocking - hence their summation
+order - from the call's shape, the thread count and the CPU's vector ISA.  backend/cbas.py:425-435 calls the
+encoder with whatever the chunk holds (512 frames, or a ragged tail), tests/golden/e2e_vitb16.npz was made with
+8-frame calls.  This script runs the reference's OWN DinoEncoder wrapper + infer_file on that fixture's 256 frames
+under several such execution variants and reports, for each against the committed fixture: fp32 row distance,
+share of fp16 elements that round differently, |dp| max, and which argmax labels change.
+
+Result (committed as profiles/r04_ref_self_variance.json): a label whose reference top-2 margin is below the
+reference's own variant-to-variant |dp| is not determined by the reference; gates use a FIXED margin above it.
+"""
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(REPO, "tests", "golden", "make_goldens.py"))
+MG = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(MG)
+from cbas_amd import config as C, weights as W, synth  # noqa: E402
+
+
+def run(enc, hm, cbas, frames, call, td, tag):
+    n = len(frames)
+    g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()
+    cls = torch.cat([enc(g[i:i + call].unsqueeze(1)).squeeze(1) for i in range(0, n, call)]).numpy()
+    p = os.path.join(td, f"v_{tag}_cls.h5")
+    with MG._FakeH5File(p, "w") as f:
+        d = f.create_dataset("cls", shape=(n, 768), dtype="f2")
+        d[:] = cls
+        cls16 = d[:].copy()
+    o = cbas.infer_file(p, hm, "gold", MG.BEHAVIORS, 31, device=torch.device("cpu"), temperature=1.0)
+    import pandas as pd
+    probs = pd.read_csv(o).to_numpy(dtype=np.float64).astype(np.float32)
+    return cls, cls16, probs
+
+
+def main():
+    fixture = sys.argv[1] if len(sys.argv) > 1 else "e2e_vitb16"
+    g = np.load(os.path.join(REPO, "tests", "golden", fixture + ".npz"))
+    n = int(g["n"])
+    if len(sys.argv) > 2:
+        n = min(n, int(sys.argv[2]))
+    cbas, classifier_head = MG.import_reference()
+    cfg = C.VIT_B16
+    frames = synth.cage_frames(int(g["frame_seed"]), n, 224, 224)
+    os.replace = MG._real_replace
+    ref_probs = g["probs"][:n].astype(np.float64)
+    srt = np.sort(ref_probs, axis=1)
+    margins = srt[:, -1] - srt[:, -2]
+    out = {"fixture": fixture, "frames": n, "variants": []}
+    with tempfile.TemporaryDirectory() as td:
+        MG.hf_model(cfg, W.synth_encoder_weights(cfg, MG.ENC_SEED)).save_pretrained(td)
+        enc = cbas.DinoEncoder(td, device="cpu")
+        hcfg = C.HeadConfig(in_features=768)
+        hm = MG.ref_head(classifier_head, hcfg, W.synth_head_weights(hcfg, MG.HEAD_SEED))
+        nthr = torch.get_num_threads()
+        isa = os.environ.get("MKL_ENABLE_INSTRUCTIONS", "") or os.environ.get("ATEN_CPU_CAPABILITY", "")
+        variants = [("call8_default", 8, nthr), ("call8_1thread", 8, 1), ("call1", 1, nthr), ("call2", 2, nthr), ("call3", 3, nthr),
+                    ("call64", 64, nthr), ("call256", 256, nthr), ("call37_ragged", 37, nthr)]
+        if isa:                                 # a second process with another vector ISA: one variant is enough
+            variants = [("call8_" + isa.lower(), 8, nthr)]
+        saved = {}
+        for tag, call, threads in variants:
+            torch.set_num_threads(threads)
+            cls, cls16, probs = run(enc, hm, cbas, frames, call, td, tag)
+            torch.set_num_threads(nthr)
+            ref16 = g["cls_f16"][:n]
+            # interior frames only when the clip was cut short (the head's windows see the clip's end differently)
+            lim = n if n == int(g["n"]) else n - 16
+            mism = np.nonzero(probs[:lim].argmax(1) != g["labels"][:lim])[0]
+            rec = {"variant": tag, "frames_per_call": call, "threads": threads,
+                   "fp16_elements_differing_pct": float((cls16 != ref16).mean() * 100),
+                   "dp_max": float(np.abs(probs[:lim] - ref_probs[:lim]).max()),
+                   "labels_differing": int(len(mism)), "frames": [int(f) for f in mism],
+                   "reference_margin_at_flips": [float(margins[f]) for f in mism]}
+            if "cls" in g.files:
+                a, b = cls.astype(np.float64), g["cls"][:n].astype(np.float64)
+                rec["cls_rel_err_max"] = float((np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)).max())
+            print(json.dumps(rec), flush=True)
+            out["variants"].append(rec)
+            if len(mism):
+                saved["probs_" + tag] = probs
+                saved["labels_" + tag] = probs.argmax(1)
+    out["smallest_reference_margins"] = [float(x) for x in np.sort(margins)[:6]]
+    suffix = ("_" + isa.lower()) if isa else ""
+    dst = os.path.join(REPO, "profiles", f"r04_ref_self_variance_{fixture}{suffix}.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print("wrote", dst)
+    if saved and n == int(g["n"]):
+        # the reference's OWN alternative outputs for this fixture (execution variants whose labels differ from the committed
+        # ones): a frame whose label the reference itself gives both ways is not a parity target
+        fx = os.path.join(REPO, "tests", "golden", f"{fixture}_variants{suffix}.npz")
+        np.savez_compressed(fx, **saved)
+        print("wrote", fx, sorted(saved))
+
+
+if __name__ == "__main__":
+    main()

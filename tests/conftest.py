@@ -36,22 +36,39 @@ def golden_dir():
     return GOLDEN
 
 
-def assert_labels_match(probs, ref_probs, prob_tol):
-    """Argmax-label parity, stated precisely: the probabilities agree within ``prob_tol`` and every
-    frame's label is identical except where the REFERENCE itself is within 2*|dp|max of a tie
-    between its top two classes (a flip there is implied by any non-bit-exact arithmetic, the
-    reference's own fp16 GPU path included).  Returns (n_mismatch, n_near_tie_frames)."""
+# Label gates use FIXED reference margins, stated here up front (r4; the r3 form forgave flips inside a band of twice the
+# measured |dp| - a band that widened with the error it was judging).
+#
+# What fixes the scale: the REFERENCE'S OWN labels are not unique below a margin.  scripts/ref_self_variance.py runs the
+# reference's DinoEncoder wrapper + infer_file on the e2e_vitb16 fixture with 1 frame per encoder call instead of 8 (the
+# reference calls its encoder with whatever a chunk holds, cbas.py:425-435): MKL picks another blocking, 0.37 % of the
+# fp16 elements it writes round the other way, probabilities move by up to 1.3e-3 and the label of frame 69 (top-2
+# margin 4.1e-5) changes (profiles/r04_ref_self_variance_e2e_vitb16.json, tests/golden/e2e_vitb16_variants.npz).
+MARGIN_FP32 = 1e-3      # precision 3 (fp32 arithmetic): no flip at any frame whose reference top-2 margin is >= this
+MARGIN_FP16 = 5e-2      # default fp16-operand mode (probabilities move by up to ~3e-2 on the synthetic head)
+
+
+def assert_labels_match(probs, ref_probs, prob_tol, margin=MARGIN_FP16, alt_labels=()):
+    """Argmax-label parity with a fixed margin: probabilities agree within ``prob_tol`` and NO label differs at a frame
+    whose reference top-2 margin is >= ``margin``.  ``alt_labels``: label vectors the reference itself produced under its
+    other execution variants - a frame whose label matches any of them counts as matching.
+    Returns (n_mismatch_vs_primary_reference, n_frames_below_margin)."""
     import numpy as np
     probs, ref_probs = np.asarray(probs, np.float64), np.asarray(ref_probs, np.float64)
     dp = float(np.abs(probs - ref_probs).max())
     assert dp <= prob_tol, f"probabilities differ by {dp:.3e} > {prob_tol:.1e}"
     s = np.sort(ref_probs, axis=1)
-    margin = s[:, -1] - s[:, -2] if ref_probs.shape[1] > 1 else np.ones(len(ref_probs))
-    mism = probs.argmax(1) != ref_probs.argmax(1)
-    near = margin <= 2.0 * dp
-    # the relaxation is always visible in the test log (-s): how many labels moved and how wide the band was
-    print(f"[labels] {int(mism.sum())} of {len(probs)} argmax labels differ; |dp|max = {dp:.3e}, near-tie band "
-          f"(reference top-2 margin <= {2.0 * dp:.3e}) holds {int(near.sum())} frames; flips outside the band: "
-          f"{int(np.sum(mism & ~near))}")
-    assert not np.any(mism & ~near), f"label flips outside the near-tie band: frames {np.nonzero(mism & ~near)[0][:10]}"
-    return int(mism.sum()), int(near.sum())
+    m = s[:, -1] - s[:, -2] if ref_probs.shape[1] > 1 else np.ones(len(ref_probs))
+    lab = probs.argmax(1)
+    mism = lab != ref_probs.argmax(1)
+    unexplained = mism.copy()
+    for alt in alt_labels:
+        unexplained &= lab != np.asarray(alt)
+    below = m < margin
+    print(f"[labels] {int(mism.sum())} of {len(probs)} argmax labels differ from the primary reference run "
+          f"({int(unexplained.sum())} of them from every reference variant); |dp|max = {dp:.3e}; fixed margin {margin:.1e}: "
+          f"{int(below.sum())} reference frames sit below it; reference margins at the differing frames: "
+          f"{np.sort(m[mism])[:8]}")
+    bad = unexplained & ~below
+    assert not np.any(bad), f"label flips at reference margins >= {margin:.1e}: frames {np.nonzero(bad)[0][:10]} margins {m[bad][:10]}"
+    return int(mism.sum()), int(below.sum())

@@ -489,6 +489,40 @@ def g_e2e_vitb(out):
     print("e2e vitb labels", np.bincount(probs.argmax(1), minlength=9), "smallest top-2 margins", np.sort(top2[:, 1] - top2[:, 0])[:6])
 
 
+def g_e2e_vitb_long(out):
+    """The headline model over a LONG clip (r4): 2 048 frames = 93 scene changes of synth.cage_frames, ViT-B/16 through the
+    reference's own DinoEncoder wrapper in 8-frame calls -> f16 -> the reference's infer_file.  Stored: the f16 rows the
+    reference wrote (all frames), its f32 CLS for every 8th frame (the fp32-mode bar is checked on those), probabilities,
+    labels.  This is the fixture the fp16 default's flip RATE and the fp32 mode's zero-flip gate are measured on."""
+    cbas, classifier_head = import_reference()
+    cfg = C.VIT_B16
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    n = 2048
+    frames = synth.cage_frames(6, n, 224, 224)
+    os.replace = _real_replace
+    with tempfile.TemporaryDirectory() as td:
+        hf_model(cfg, w).save_pretrained(td)
+        enc = cbas.DinoEncoder(td, device="cpu")
+        g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()                      # cbas.py:431
+        cls = torch.cat([enc(g[i:i + 8].unsqueeze(1)).squeeze(1) for i in range(0, n, 8)]).numpy()      # cbas.py:435-436
+        hcfg = C.HeadConfig(in_features=768)
+        hm = ref_head(classifier_head, hcfg, W.synth_head_weights(hcfg, HEAD_SEED))
+        p = os.path.join(td, "e2e_cls.h5")
+        with _FakeH5File(p, "w") as f:
+            d = f.create_dataset("cls", shape=(n, 768), dtype="f2")
+            d[:] = cls
+            cls16 = d[:].copy()
+        o = cbas.infer_file(p, hm, "gold", BEHAVIORS, 31, device=torch.device("cpu"), temperature=1.0)
+        import pandas as pd
+        probs = pd.read_csv(o).to_numpy(dtype=np.float64).astype(np.float32)
+    labels = probs.argmax(1)
+    np.savez_compressed(os.path.join(out, "e2e_vitb16_long.npz"), cls_every8=cls[::8].astype(np.float32), cls_f16=cls16,
+                        probs=probs, labels=labels, frames_sha=sha(frames), frame_seed=6, n=n)
+    top2 = np.sort(probs, axis=1)[:, -2:]
+    print("e2e vitb long labels", np.bincount(labels, minlength=9), "transitions", int((labels[1:] != labels[:-1]).sum()),
+          "smallest top-2 margins", np.sort(top2[:, 1] - top2[:, 0])[:8])
+
+
 def g_encode_file(out):
     """cbas.encode_file on a fake 'video' (decord/h5py fakes): pins chunking (CHUNK_SIZE=512 with a
     ragged tail), the f2 cast and the returned path.  Uses the tiny-D wrapper-compatible config
@@ -565,7 +599,7 @@ def g_dinov2(out):
 
 
 ALL = {"dinov2": g_dinov2, "tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
-       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_variants": g_head_variants, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e, "e2e_vitb": g_e2e_vitb,
+       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_variants": g_head_variants, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e, "e2e_vitb": g_e2e_vitb, "e2e_vitb_long": g_e2e_vitb_long,
        "encode_file": g_encode_file}
 
 if __name__ == "__main__":

@@ -101,7 +101,7 @@ def test_sampled_oracle_agreement(clip_run):
     idx = H.infer_windows(cls16, 31)[sel]
     logits, _ = H.head_forward(cls16.astype(np.float32)[idx], clip_run["head_w"], 31)
     ref_p = H.softmax_T(logits, 1.0)
-    n_mis, _ = assert_labels_match(clip_run["probs"][sel].cpu().numpy(), ref_p, 1e-4)
+    n_mis, _ = assert_labels_match(clip_run["probs"][sel].cpu().numpy(), ref_p, 1e-4, margin=0.0)   # same rows in: every label
     assert n_mis == 0
 
 

@@ -240,10 +240,11 @@ def test_e2e_config1(golden_dir):
     assert r.max() < CLS_TOL + 5e-4          # includes the fp16 storage rounding (2^-11)
     probs = probs.cpu().numpy()
     # fp16 encoder (CLS within 1e-3) -> probabilities within 1e-2; labels identical outside near-ties
-    n_mis, n_near = assert_labels_match(probs, g["probs"], 1e-2)      # no flip outside the near-tie band (prints the band)
-    # Inside the band: identical labels cannot be promised by ANY arithmetic that is not bit-identical to the fp32 CPU
-    # path (the reference's own fp16-autocast GPU path included), so what is pinned is how narrow the exception is: at
-    # most one frame of this clip, and only where the reference's own top-2 margin is under 1e-2.
+    n_mis, n_near = assert_labels_match(probs, g["probs"], 1e-2)      # fixed margin (conftest.MARGIN_FP16): no flip at or above it
+    # Below it: identical labels cannot be promised by the fp16-operand arithmetic (the reference's own fp16-autocast GPU
+    # path has the same property; precision 3 is the mode that reproduces them, tests/test_gpu_fp32.py), so what is pinned
+    # is how narrow the exception is: at most one frame of this clip, and only where the reference's own top-2 margin is
+    # under 1e-2.
     ref = g["probs"].astype(np.float64)
     srt = np.sort(ref, axis=1)
     flips = np.nonzero(probs.argmax(1) != ref.argmax(1))[0]
@@ -262,9 +263,9 @@ def test_e2e_config1(golden_dir):
 def test_e2e_config2_model_vitb(golden_dir):
     """The headline model end to end against the reference's own wrapper + infer_file (tests/golden/e2e_vitb16.npz: ViT-B/16,
     256 frames 224^2, C = 9): CLS within the 1e-3 contract on every frame (measured 6.3e-4), probabilities within 3e-2
-    (measured 1.9e-2, at the clip's one behaviour transition, where the head's probabilities are steepest), labels identical
-    except where the reference's own top-2 margin is under 1e-2 (two such frames, margins 4e-5 and 6e-3; measured: 1 flip of
-    256, on one of them)."""
+    (measured 1.9e-2, at a behaviour transition, where the head's probabilities are steepest), no label flip at a
+    reference top-2 margin >= conftest.MARGIN_FP16, and at most two flips in all, only under 1e-2 (two such frames, margins
+    4e-5 and 6e-3; measured: 1 flip of 256, on one of them).  The fp32 mode's strict gate: tests/test_gpu_fp32.py."""
     from cbas_amd.encoder import DinoEncoder
     from cbas_amd.head import ClassifierLSTMDeltas
     from cbas_amd.stream import ClipStream
@@ -297,6 +298,44 @@ def test_e2e_config2_model_vitb(golden_dir):
     np.testing.assert_allclose(p_same, g["probs"], atol=1e-4)
     assert (p_same.argmax(1) == g["labels"]).all()
     enc.close(); head.close()
+
+
+def test_e2e_long_clip_flip_rate_fp16(golden_dir):
+    """The default fp16-operand mode on 2 048 frames of the headline model with 122 behaviour transitions
+    (tests/golden/e2e_vitb16_long.npz, the reference's own wrapper + infer_file): the flip RATE and where the flips sit on
+    the reference's top-2 margin scale.  Fixed gates: no flip at a reference margin >= conftest.MARGIN_FP16, at most 1 % of
+    the labels differ, probabilities within 5e-2.  (precision 3 reproduces all 2 048: tests/test_gpu_fp32.py.)"""
+    from cbas_amd.encoder import DinoEncoder
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from cbas_amd.stream import ClipStream
+    g = load(golden_dir, "e2e_vitb16_long")
+    n = int(g["n"])
+    cfg = C.VIT_B16
+    fr = synth.cage_frames(int(g["frame_seed"]), n, 224, 224)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(224, 224))
+    head = ClassifierLSTMDeltas(768, 9)
+    head.load_state_dict(W.synth_head_weights(C.HeadConfig(in_features=768), 4321))
+    head.to("cuda")
+    try:
+        st = ClipStream(enc, head, capacity=n)
+        for i in range(0, n, 64):
+            st.push_u8(torch.from_numpy(fr[i:i + 64]).cuda())
+        cls16, probs = st.finish()
+        torch.cuda.synchronize()
+        probs = probs.cpu().numpy()
+        r = rel_rows(cls16.float().cpu().numpy()[::8], g["cls_every8"])
+        assert r.max() < CLS_TOL + 5e-4
+        n_mis, n_below = assert_labels_match(probs, g["probs"], 5e-2)
+        srt = np.sort(g["probs"].astype(np.float64), axis=1)
+        m = srt[:, -1] - srt[:, -2]
+        flips = np.nonzero(probs.argmax(1) != g["labels"])[0]
+        edges = [0.0, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 1.0]
+        print(f"[e2e_vitb16_long fp16] {n_mis} of {n} labels differ ({n_mis / n * 100:.2f} %); reference frames per margin bin "
+              f"{edges}: {np.histogram(m, edges)[0].tolist()}, flips per bin: {np.histogram(m[flips], edges)[0].tolist()}; "
+              f"CLS rel err max {r.max():.3e}")
+        assert n_mis <= n // 100
+    finally:
+        enc.close(); head.close()
 
 
 def test_encode_file_and_infer_file_dropins(golden_dir, tmp_path):
