@@ -264,6 +264,22 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     if world > 1:
         barrier()          # every rank is here; on RCCL this also creates the communicator the transfers below share
     queue_ = _ClipQueue(len(paths), store, prefix)
+    dead_after = float(os.environ.get("CBAS_GATHER_DEAD_AFTER", "120"))
+    hb_stop = threading.Event()
+    hb = None
+    if store is not None:
+        hb_store = store.clone() if hasattr(store, "clone") else store
+
+        def heartbeat():
+            while True:
+                try:
+                    hb_store.set(f"{prefix}hb{rank}", repr(time.time()))
+                except Exception:  # noqa: BLE001 - the store is going away with the job
+                    return
+                if hb_stop.wait(1.0):
+                    return
+        hb = threading.Thread(target=heartbeat, name="cbas-heartbeat", daemon=True)
+        hb.start()
     runner = P.ClipRunner(encoder, head, temperature, sessions=2 if nccl else 1)
     dev = encoder.device if nccl else torch.device("cpu")
 
@@ -305,10 +321,29 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 st = store.clone() if store is not None and hasattr(store, "clone") else store
                 for k in range(len(paths)):                # exactly one ticket per clip
                     key = f"{prefix}t{k}"
+                    waited = 0
                     while not (key in tickets if st is None else st.check([key])):
                         if stop.is_set():
                             return
                         time.sleep(0.001)
+                        waited += 1
+                        # Liveness (about once a second): a rank that has LEFT has published every ticket it was going to
+                        # (its `finally` marks the clips it took but did not deliver as failed first); a rank whose
+                        # heartbeat has stopped for `dead_after` seconds will publish nothing more.  When every rank is one
+                        # or the other, the tickets still missing will never come: the clips without one stay "failed"
+                        # in the records and the receiver returns instead of blocking rank 0 for ever.
+                        if st is not None and waited % 1000 == 0 and not st.check([key]):
+                            now = time.time()
+                            gone = 0
+                            for r in range(world):
+                                if st.check([f"{prefix}left{r}"]):
+                                    gone += 1
+                                elif st.check([f"{prefix}hb{r}"]) and now - float(st.get(f"{prefix}hb{r}").decode()) > dead_after:
+                                    print(f"cbas_amd.encode_files: rank {r} has not been heard from for {dead_after:.0f} s; "
+                                          "its outstanding clips are marked failed")
+                                    gone += 1
+                            if gone == world and not st.check([key]):
+                                return
                     take(tickets.pop(key) if st is None else json.loads(st.get(key).decode()))
             except BaseException as e:  # noqa: BLE001 - re-raised by the caller after the join
                 recv_err.append(e)
@@ -318,7 +353,11 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
         receiver = threading.Thread(target=receive, name="cbas-gather", daemon=True)
         receiver.start()
 
+    taken: set = set()                                     # clips this rank drew from the queue ...
+    published: set = set()                                 # ... and the ones it has published a ticket for
+
     def publish(clip: int, status: int, n: int, has_probs: bool):
+        published.add(clip)
         t = {"rank": rank, "clip": clip, "status": status, "n": int(n), "probs": bool(has_probs)}
         if store is None:
             tickets[f"{prefix}t{clip_seq[0]}"] = t
@@ -382,9 +421,11 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 clip, prepared = queue_.next(), None
             if clip is None:
                 break
+            taken.add(clip)
             if pool is not None and queue_.remaining() >= world:
                 nxt = queue_.next()
                 if nxt is not None:
+                    taken.add(nxt)
                     ahead = (nxt, pool.submit(runner.prepare, paths[nxt]))
             try:
                 if pipelined:
@@ -432,9 +473,24 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 pass
         if pool is not None:
             pool.shutdown(wait=True)
+        # every clip this rank took from the queue gets exactly one ticket, whatever happened to it: a clip drawn early
+        # for look-ahead, or one whose delivery raised outside the per-clip handlers, would otherwise leave rank 0's
+        # receiver waiting for a ticket that never comes
+        for c in sorted(taken - published):
+            try:
+                print(f"ERROR during encoding for {paths[c]} on rank {rank}: not delivered (this rank is leaving early)")
+                publish(c, _ST_FAILED, 0, False)
+            except Exception:  # noqa: BLE001
+                pass
+        if store is not None:
+            hb_stop.set()
+            try:
+                store.set(f"{prefix}left{rank}", "1")
+            except Exception:  # noqa: BLE001
+                pass
         if rank == 0:
-            if not finished:
-                stop.set()                                 # an error is on its way up: do not wait for tickets that will not come
+            if not finished and world == 1:
+                stop.set()                                 # an error is on its way up and nobody else can publish: do not wait
             receiver.join()
             writer.close()
         runner.close()
@@ -584,12 +640,40 @@ def encode_infer_file_sharded(path: str, encoder, head=None, dataset_name: Optio
     if head is not None and (dataset_name is None or behaviors is None):
         raise ValueError("classification needs dataset_name and behaviors (infer_file's arguments)")
     D = encoder.config.hidden_size
-    reader = P.open_video(path)
+    dev = encoder.device if _on_gpu(encoder) else torch.device("cpu")
+
+    def agree(err: Optional[BaseException], what: str, value: int = 0) -> None:
+        """Every rank arrives here whether or not its own step failed; ALL ranks leave by raising when ANY failed (or when
+        they disagree on ``value``), so no rank goes on into a collective the others have abandoned: a clip that cannot be
+        read in one rank's frame range is skipped on every rank together (the caller logs it and takes the next video, as
+        EncodeThread does: workthreads.py:334-336) instead of hanging the job."""
+        if world > 1:
+            t = torch.tensor([0 if err is not None else 1, value, -value], dtype=torch.int64,
+                             device="cpu" if dist.get_backend() == "gloo" else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok, vmin, vmax = bool(t[0].item()), int(t[1].item()), -int(t[2].item())
+        else:
+            ok, vmin, vmax = err is None, value, value
+        if err is not None:
+            raise err
+        if not ok:
+            raise RuntimeError(f"{path}: {what} failed on another rank; the clip is skipped on every rank")
+        if vmin != vmax:
+            raise RuntimeError(f"{path}: the ranks do not see the same video ({vmin} .. {vmax} frames)")
+
+    reader, n, err = None, 0, None
     try:
+        reader = P.open_video(path)
         if getattr(reader, "decodes_ahead", False) and world > 1:
             raise RuntimeError(f"{path}: its frame source reads sequentially; a clip can only be split over ranks with a "
                                "random-access reader")
         n = len(reader)
+        if head is not None and hasattr(head, "to"):
+            head.to(dev)
+    except Exception as e:  # noqa: BLE001 - agreed on below
+        err = e
+    try:
+        agree(err, "opening the video", n)
         if n == 0:
             if rank == 0:
                 print(f"Warning: Video {path} contains no frames. Skipping.")
@@ -598,16 +682,29 @@ def encode_infer_file_sharded(path: str, encoder, head=None, dataset_name: Optio
         runner = P.ClipRunner(encoder, None)
         try:
             rows = None
-            if b > a:
-                res = runner.run(path, _FrameRange(reader, a, b), progress_callback if rank == 0 else None, device_out=True)
-                rows = res.rows if isinstance(res.rows, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(res.rows))
-            if rows is None:
-                rows = torch.empty((0, D), dtype=torch.float16, device=encoder.device if _on_gpu(encoder) else "cpu")
+            try:
+                if b > a:
+                    res = runner.run(path, _FrameRange(reader, a, b), progress_callback if rank == 0 else None, device_out=True)
+                    rows = res.rows if isinstance(res.rows, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(res.rows))
+                if rows is None:
+                    rows = torch.empty((0, D), dtype=torch.float16, device=dev)
+            except Exception as e:  # noqa: BLE001
+                err = e
+            agree(err, f"encoding frames of a rank's range")
             probs = None
             if head is not None:
-                if hasattr(head, "to"):
-                    head.to(rows.device)
-                probs = classify_sharded(head, rows, temperature).contiguous()
+                # classify_sharded, with the agreement between its exchange step and the rank-local head call
+                half = head.seq_len // 2
+                left, right = exchange_halo(rows, half)
+                try:
+                    buf = torch.cat([left, rows, right]).contiguous()
+                    pr = torch.empty((buf.shape[0], head.out_features), dtype=torch.float32, device=buf.device)
+                    if rows.shape[0]:
+                        head.infer_range_into(buf, buf.shape[0], left.shape[0], rows.shape[0], pr, temperature)
+                    probs = pr[left.shape[0]:left.shape[0] + rows.shape[0]].contiguous()
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                agree(err, "classifying a rank's range")
             g_rows = gather_rows([rows.contiguous()], dst=0)
             g_probs = gather_rows([probs], dst=0) if probs is not None else None
             if rows.is_cuda:
@@ -627,7 +724,7 @@ def encode_infer_file_sharded(path: str, encoder, head=None, dataset_name: Optio
         finally:
             runner.close()
     finally:
-        if hasattr(reader, "close"):
+        if reader is not None and hasattr(reader, "close"):
             reader.close()
 
 

@@ -863,55 +863,55 @@ class ClipRunner:
         if chunks is None:
             chunks = _chunks(reader, video_len, pinned=True, piece=PIECE)
         with contextlib.closing(chunks):
-            for i, _end_index, frames in chunks:
-                _progress(progress_callback, i, video_len)
-                frames = np.ascontiguousarray(frames)
-                if ent is None:
-                    enc._fit_frame(frames.shape[1], frames.shape[2])     # may rebuild the handle (closes sessions)
-                    ent = self._session(video_len)
-                    if rows_sink is not None and wait and not device_out and os.environ.get("CBAS_ROWS_STREAM") != "0":
-                        ent[0].stream_rows_to(video_len)
-                        pump = _RowsPump(ent[0], rows_sink)
-                try:
-                    if pump is not None and pump.error is not None:      # the file cannot be written: stop encoding for it
+            try:
+                for i, _end_index, frames in chunks:
+                    _progress(progress_callback, i, video_len)
+                    frames = np.ascontiguousarray(frames)
+                    if ent is None:
+                        enc._fit_frame(frames.shape[1], frames.shape[2])     # may rebuild the handle (closes sessions)
+                        ent = self._session(video_len)
+                        if rows_sink is not None and wait and not device_out and os.environ.get("CBAS_ROWS_STREAM") != "0":
+                            ent[0].stream_rows_to(video_len)
+                            pump = _RowsPump(ent[0], rows_sink)
+                    if pump is not None and pump.error is not None:          # the file cannot be written: stop encoding for it
                         raise pump.error
-                    ent[0].push_host(frames, channel=1)                  # green channel, cbas.py:431
-                except BaseException:
-                    if pump is not None:
-                        pump.abort()
-                    raise
-                sub += -(-frames.shape[0] // enc.max_batch)
-                # a slot's previous host->HBM copy has completed when the slot is submitted to again, i.e. ENC_SLOTS
-                # sub-batches later (cbas_enc_submit_u8_host_dev): only then may the decoder refill this chunk's buffer
-                held.append((frames, sub + _lib.ENC_SLOTS))
-                while held and held[0][1] <= sub:
-                    chunks.release(held.popleft()[0])
-            sess = ent[0]
-            if not wait:
-                # the ring buffers this clip still reads from are released when its last copies are known to be done:
-                # the pending result does that (it is resolved one clip later, with the ring long since given back, so
-                # the buffers go back to the process-wide pool rather than to this stream's ring)
-                rows, probs, ev = sess.finish_host_async()
-                res = ClipResult(rows, probs if self.head is not None else None, False)
-                return _PendingClip(res, ev, chunks.detach_ring())
-            if device_out:
-                rows, probs = sess.finish()
-                torch.cuda.current_stream(enc.device).synchronize()      # every copy out of the ring has completed
-                res = ClipResult(rows, probs if self.head is not None else None, True, ent[1])
-            else:
-                try:
+                    ent[0].push_host(frames, channel=1)                      # green channel, cbas.py:431
+                    sub += -(-frames.shape[0] // enc.max_batch)
+                    # a slot's previous host->HBM copy has completed when the slot is submitted to again, i.e. ENC_SLOTS
+                    # sub-batches later (cbas_enc_submit_u8_host_dev): only then may the decoder refill this chunk's buffer
+                    held.append((frames, sub + _lib.ENC_SLOTS))
+                    while held and held[0][1] <= sub:
+                        chunks.release(held.popleft()[0])
+                sess = ent[0]
+                if not wait:
+                    # the ring buffers this clip still reads from are released when its last copies are known to be done:
+                    # the pending result does that (it is resolved one clip later, with the ring long since given back, so
+                    # the buffers go back to the process-wide pool rather than to this stream's ring)
+                    rows, probs, ev = sess.finish_host_async()
+                    res = ClipResult(rows, probs if self.head is not None else None, False)
+                    return _PendingClip(res, ev, chunks.detach_ring())
+                if device_out:
+                    rows, probs = sess.finish()
+                    torch.cuda.current_stream(enc.device).synchronize()      # every copy out of the ring has completed
+                    res = ClipResult(rows, probs if self.head is not None else None, True, ent[1])
+                else:
                     rows, probs = sess.finish_host()
-                except BaseException:
                     if pump is not None:
-                        pump.abort()
-                    raise
+                        pump.finish(rows.shape[0])                           # the sink has every row now (its error surfaces here)
+                    elif rows_sink is not None:
+                        rows_sink.append(rows)
+                    res = ClipResult(rows, probs if self.head is not None else None, False)
+                while held:
+                    chunks.release(held.popleft()[0])
+            except BaseException:
+                # ANY way out of the clip other than its normal end - a reader / decode error raised by the `chunks`
+                # iterator mid-clip, an exception from the progress callback, a failed push or finish - must leave no
+                # "cbas-rows-out" thread behind: it would keep polling a session that the next clip resets (a second
+                # consumer of cbas_fused_rows_ready) and could still be inside sink.append (libhdf5 is not thread-safe)
+                # while the caller removes the .tmp file.  abort() joins the thread; it is idempotent.
                 if pump is not None:
-                    pump.finish(rows.shape[0])                           # the sink has every row now (its error surfaces here)
-                elif rows_sink is not None:
-                    rows_sink.append(rows)
-                res = ClipResult(rows, probs if self.head is not None else None, False)
-            while held:
-                chunks.release(held.popleft()[0])
+                    pump.abort()
+                raise
         return res
 
 

@@ -179,8 +179,24 @@ class LatencyEncoder(StubEncoder):
         super().submit_host(slot, frames, channel)
 
 
-def _timed_worker(rank, world, port, td, q, per_frame, write_s):
+class LatencyHead(StubHead):
+    """A head that costs `seconds` per clip (the real one: 16 ms for 18 000 frames on the GPU) and whose stand-in
+    arithmetic is O(n) - the window-mean head above costs 0.5 s of CPU per 18 000-frame clip, which is the stand-in's cost,
+    not the product's."""
+
+    def __init__(self, seconds):
+        super().__init__()
+        self.seconds = seconds
+
+    def infer_range_into(self, cls_rows, n_frames, first, count, probs_out, temperature=1.0):
+        import time
+        time.sleep(self.seconds)
+        probs_out[first:first + count] = torch.softmax(cls_rows[first:first + count, :C_].float() * 4.0 / max(1e-3, temperature), dim=1)
+
+
+def _timed_worker(rank, world, port, td, q, per_frame, write_s, head_s=None):
     import time
+    torch.set_num_threads(1)                               # ranks share this container's 8 cores: no oversubscription
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     cdist.init_from_env("gloo")
     if write_s:                                            # a slow disk under rank 0's writers
@@ -191,27 +207,29 @@ def _timed_worker(rank, world, port, td, q, per_frame, write_s):
             return real(*a, **k)
         P.write_cls_file = slow_write
     paths = sorted(p for p in (os.path.join(td, f) for f in os.listdir(td)) if p.endswith(".npy"))
-    enc, head = LatencyEncoder(per_frame), StubHead()
-    dist.barrier()
+    enc, head = LatencyEncoder(per_frame), (StubHead() if head_s is None else LatencyHead(head_s))
+    cdist.barrier()
     t0 = time.perf_counter()
     recs = cdist.encode_files(paths, enc, head=head, dataset_name="gold", behaviors=NAMES)
-    dist.barrier()
+    cdist.barrier()
     wall = time.perf_counter() - t0
     if rank == 0:
         q.put((wall, recs))
-    dist.barrier()
-    dist.destroy_process_group()
+    cdist.barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
-def _run_timed(tmp_path, world, lengths, per_frame, write_s):
+def _run_timed(tmp_path, world, lengths, per_frame, write_s, head_s=None):
     td = str(tmp_path)
+    os.makedirs(td, exist_ok=True)
     rng = np.random.default_rng(3)
     for i, n in enumerate(lengths):
         np.save(os.path.join(td, f"clip{i:02d}.npy"), rng.integers(0, 200, (n, 8, 8, 3), dtype=np.uint8))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, td, q, per_frame, write_s)) for r in range(world)]
+    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, td, q, per_frame, write_s, head_s)) for r in range(world)]
     for p in procs:
         p.start()
     wall, recs = q.get(timeout=240)
@@ -318,3 +336,158 @@ def test_one_clip_split_over_ranks_writes_the_single_process_files(tmp_path, wor
             assert (_sha(h5), _sha(csv)) == want[name], name
     assert enc_only[1] is None and _sha(enc_only[0]) == want_only
 
+
+
+# ---- failure handling at world > 1 ----------------------------------------------------------------------------
+class _RangeFailReader:
+    """`.failnpy`: an .npy clip whose frames from index 900 on cannot be decoded (a damaged tail)."""
+
+    def __init__(self, path):
+        self._a = np.load(path[:-len(".failnpy")] + ".npy", mmap_mode="r")
+
+    def __len__(self):
+        return self._a.shape[0]
+
+    def get_batch(self, indices):
+        idx = np.asarray(list(indices))
+        if len(idx) and idx.max() >= 900:
+            raise IOError("damaged frame data")
+        return np.asarray(self._a[idx])
+
+
+def _sharded_fail_worker(rank, world, port, td, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    cdist.init_from_env("gloo")
+    P.register_reader(".failnpy", _RangeFailReader)
+    out = []
+    for name in ("bad.failnpy", "missing.npy", "good.npy"):      # damaged in rank 1's range; unreadable everywhere; fine
+        try:
+            out.append(("ok", cdist.encode_infer_file_sharded(os.path.join(td, name), FrameExactEncoder(), head=StubHead(),
+                                                               dataset_name="gold", behaviors=NAMES, temperature=0.9)))
+        except Exception as e:  # noqa: BLE001 - what the CLI's loop does: log, barrier, next video
+            out.append(("error", f"{type(e).__name__}: {e}"))
+        dist.barrier()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_clip_with_a_failure_on_one_rank_is_skipped_by_all_ranks_together(tmp_path):
+    """A clip that cannot be decoded inside rank 1's frame range (frames 600-1199 of 1200, damaged from 900 on): rank 1's
+    error must not leave rank 0 alone in the halo all_gather / the gather.  Both ranks agree on the failure before any data
+    collective and raise; the next video - on the same process group - is encoded normally, byte for byte."""
+    td = str(tmp_path)
+    rng = np.random.default_rng(21)
+    fr = rng.integers(0, 200, (1200, 8, 8, 3), dtype=np.uint8)
+    np.save(os.path.join(td, "bad.npy"), fr)
+    open(os.path.join(td, "bad.failnpy"), "w").close()
+    np.save(os.path.join(td, "good.npy"), fr)
+    ref = str(tmp_path / "ref")
+    os.makedirs(ref)
+    np.save(os.path.join(ref, "good.npy"), fr)
+    h5 = P.encode_file(FrameExactEncoder(), os.path.join(ref, "good.npy"))
+    want = (_sha(h5), _sha(P.infer_file(h5, StubHead(), "gold", NAMES, 31, device="cpu", temperature=0.9)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_fail_worker, args=(r, 2, port, td, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        (s_bad, m_bad), (s_miss, _m), (s_good, r_good) = got[rank]
+        assert s_bad == "error" and s_miss == "error" and s_good == "ok", got[rank]
+    assert "damaged frame data" in got[1][0][1]                       # the rank that hit it reports the cause ...
+    assert "another rank" in got[0][0][1]                             # ... the other one says why it skipped
+    assert (_sha(got[0][2][1][0]), _sha(got[0][2][1][1])) == want and got[1][2][1] == (None, None)
+    assert not os.path.exists(os.path.join(td, "bad_cls.h5"))
+
+
+class _AbortOnClip(StubEncoder):
+    """Raises something that is NOT an Exception while encoding a marked clip: the rank leaves encode_files through its
+    `finally`, as with a KeyboardInterrupt or a bug outside the per-clip handlers."""
+
+    def submit_host(self, slot, frames, channel=1):
+        if frames[0, 0, 0, 0] == 251:
+            raise SystemExit("rank leaves early")
+        super().submit_host(slot, frames, channel)
+
+
+def _leaver_worker(rank, world, port, td, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      CBAS_GATHER_DEAD_AFTER="5")
+    cdist.init_from_env("gloo")
+    paths = sorted(p for p in (os.path.join(td, f) for f in os.listdir(td)) if p.endswith(".npy"))
+    left_early = False
+    try:
+        recs = cdist.encode_files(paths, _AbortOnClip() if rank == 1 else LatencyEncoder(0.0005), head=StubHead(), dataset_name="gold",
+                                  behaviors=NAMES)
+    except SystemExit:
+        recs, left_early = None, True
+    q.put((rank, left_early, recs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_leaves_early_fails_its_clips_and_rank0_returns(tmp_path):
+    """Rank 1 leaves encode_files by a non-Exception in the middle of its first clip.  Its `finally` publishes FAILED
+    tickets for the clips it had drawn, so rank 0's receiver gets one ticket per clip, writes everybody else's files and
+    returns - it used to wait for ever for the tickets of a rank that was gone."""
+    td = str(tmp_path)
+    rng = np.random.default_rng(9)
+    for i in range(6):
+        fr = rng.integers(0, 200, (60, 8, 8, 3), dtype=np.uint8)
+        np.save(os.path.join(td, f"clip{i}.npy"), fr)
+    poison = rng.integers(0, 200, (60, 8, 8, 3), dtype=np.uint8)
+    poison[0, 0, 0, 0] = 251
+    np.save(os.path.join(td, "clip6.npy"), poison)                   # only rank 1's encoder reacts to it
+    np.save(os.path.join(td, "clip0.npy"), poison)                   # first in the queue: whoever draws it
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_leaver_worker, args=(r, 2, port, td, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, left, recs = q.get(timeout=120)
+        got[rank] = (left, recs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    recs = got[0][1]
+    assert recs is not None and len(recs) == 7
+    failed = [r for r in recs if r["status"] == "failed"]
+    ok = [r for r in recs if r["status"] == "ok"]
+    if got[1][0]:                                                    # rank 1 drew a poisoned clip and left
+        assert 1 <= len(failed) <= 3 and all(r["rank"] == 1 for r in failed), failed
+    assert len(ok) + len(failed) == 7 and all(os.path.exists(r["cls_file"]) and os.path.exists(r["csv_file"]) for r in ok)
+
+
+# ---- cfg3 rehearsed at world 8 (VERDICT r3 item 7) ------------------------------------------------------------------------
+def test_cfg3_rehearsal_eight_ranks_one_18000_frame_clip_each(tmp_path):
+    """BASELINE configs[2] on CPU stand-ins: 8 ranks x one 18 000-row clip, with the per-clip costs MEASURED on the GPU box
+    (0.81 s to encode such a clip, 16 ms for the head, 22 ms for its `_cls.h5` on rank 0's one HDF5
+    thread).  Checks the ticket / receiver ordering at world 8 (every rank takes exactly one clip, all 8 x 18 000 rows
+    arrive, every file is written) and the capacity arithmetic of rank 0.
+
+    What the rehearsal shows (r4): 'the writer is 25 % busy' holds in steady state, but with ONE clip per rank all eight
+    clips end at the same moment and their eight `_cls.h5` writes queue on the one HDF5 thread AFTER the encode: the job is
+    encode + 8 x write = 0.81 + 0.18 s = 1.22 x the single-rank clip, not 1.0 x (measured here: ~1.35 x with this
+    container's 8 cores shared by 8 Python ranks).  The VERDICT's 1.15 x is therefore not met by this design at exactly
+    one clip per GPU; the bound asserted is the arithmetic one.  The fix would be rows gathered WHILE the clip runs."""
+    n = 18000
+    per_frame, write_s = 0.81 / n, 0.022
+    one, _ = _run_timed(tmp_path / "one", 1, [n], per_frame=per_frame, write_s=write_s, head_s=0.016)
+    wall, recs = _run_timed(tmp_path / "eight", 8, [n] * 8, per_frame=per_frame, write_s=write_s, head_s=0.016)
+    taken = [sum(1 for r in recs if r["rank"] == k) for k in range(8)]
+    print(f"cfg3 rehearsal: one rank, one clip {one:.3f} s; eight ranks, eight clips {wall:.3f} s = {wall / one:.3f} x; "
+          f"clips per rank {taken}; aggregate {8 * n / wall:.0f} rows/s against {n / one:.0f} on one rank "
+          f"({8 * n / wall / (n / one):.2f} x of 8)")
+    assert taken == [1] * 8
+    assert sum(r["frames"] for r in recs) == 8 * n
+    assert wall <= one + 8 * write_s + 0.35            # encode + the eight serial writes + process noise of this container
+    assert 8 * n / wall >= 5.0 * (n / one)             # at least 5 x one rank's rate even in this worst case for the tail
