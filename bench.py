@@ -263,6 +263,11 @@ def main() -> None:
     ap.add_argument("--clip-format", choices=("npy", "avi"), default="npy",
                     help="files_path clips: raw uint8 frames (.npy) or Motion-JPEG AVI (real decoder work in the loop)")
     ap.add_argument("--files-dir", default=None, help="where the synthetic clips go (default: a temp dir under /dev/shm)")
+    ap.add_argument("--host-input", choices=("green", "rgb"), default="green",
+                    help="`value` pass: how the pinned RGB frames reach the device.  green (default, r4): a decode-ahead thread "
+                         "keeps channel 1 while it fills page-locked ring pieces (cbas_pick_channel_u8), as the file paths do - "
+                         "50 176 bytes per 224x224 frame cross PCIe (SURVEY section 8(d)); rgb: the r3 form - the RGB bytes are "
+                         "DMA'd as they are (150 528 per frame) and the device picks the channel")
     ap.add_argument("--preroll-seconds", type=float, default=1.0,
                     help="untimed steady-state work right before each timed pass, besides the W warm-up steps: a short run "
                          "(the driver's --steps 20 is 58 ms) otherwise starts from an idle device - clocks down, power "
@@ -317,12 +322,68 @@ def main() -> None:
             stream.push_u8(clip[o:o + B])
         return stream.finish()
 
+    class _PinnedClip:
+        """The pinned RGB clip as a frame source (what decord hands encode_file, already in page-locked memory); wraps
+        around after n_res frames like run() does."""
+        frame_shape = (args.hw, args.hw, 3)
+
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def _spans(self, a, b):
+            while a < b:
+                o = a % n_res
+                m = min(b - a, n_res - o)
+                yield a, o, m
+                a += m
+
+        def read_channel_into(self, a, b, ch, out):
+            from cbas_amd import pipeline as P
+            for a0, o, m in self._spans(a, b):
+                P.pick_channel(clip_host[o:o + m], ch, out[a0 - a:a0 - a + m])
+
+        def read_into(self, a, b, out):
+            for a0, o, m in self._spans(a, b):
+                np.copyto(out[a0 - a:a0 - a + m], clip_host[o:o + m])
+
+        def get_batch(self, idx):
+            return clip_host[np.asarray(list(idx)) % n_res]
+
+    def push_host_frames(steps: int):
+        """The frames of `steps` 64-frame batches from pinned host memory into the session; returns a closer to call once
+        every host -> HBM copy has completed (the page-locked ring goes back to its pool)."""
+        if args.host_input == "rgb":
+            for s_ in range(steps):
+                o = (s_ * B) % n_res
+                stream.push_host(clip_host[o:o + B])
+            return lambda: None
+        from collections import deque
+        from cbas_amd import pipeline as P, _lib as L
+        piece = B if (B > P.PIECE and P.CHUNK_SIZE % B == 0) else P.PIECE        # whole batches per ring piece
+        chunks = P._chunks(_PinnedClip(steps * B), steps * B, pinned=True, piece=piece)
+        held, sub = deque(), 0
+        try:
+            for _i, _end, frames in chunks:
+                stream.push_host(frames)                    # (n, H, W) green planes in a page-locked ring piece
+                sub += -(-frames.shape[0] // B)
+                held.append((frames, sub + L.ENC_SLOTS))    # a slot's copy is done when the slot is submitted to again
+                while held and held[0][1] <= sub:
+                    chunks.release(held.popleft()[0])
+        except BaseException:
+            chunks.close()
+            raise
+        return chunks.close
+
     def run_host(steps: int):
         stream.reset()
-        for s in range(steps):
-            o = (s * B) % n_res
-            stream.push_host(clip_host[o:o + B])
-        return stream.finish_host()               # numpy arrays in host memory
+        done = push_host_frames(steps)
+        try:
+            return stream.finish_host()           # numpy arrays in host memory; every copy has completed
+        finally:
+            done()
 
     def gather(cls16, probs):
         if world > 1:
@@ -347,8 +408,9 @@ def main() -> None:
             fn(preroll_steps)
         torch.cuda.synchronize(device)
 
-    def timed():
-        preroll(run)
+    def timed(pre: bool = True):
+        if pre:
+            preroll(run)
         cdist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
@@ -364,20 +426,22 @@ def main() -> None:
         if world == 1:
             return run_host(steps)
         stream.reset()
-        for s in range(steps):
-            o = (s * B) % n_res
-            stream.push_host(clip_host[o:o + B])
-        if rank == 0:
-            c16h, prh = stream.finish_host()
-            g16 = cdist.gather_rows([torch.empty((0, cfg.hidden_size), dtype=torch.float16, device=device)], dst=0)
-            gpr = cdist.gather_rows([torch.empty((0, BEHAVIORS), dtype=torch.float32, device=device)], dst=0)
-            hosted = [(t[0].cpu(), u[0].cpu()) for t, u in zip(g16[1:], gpr[1:])]       # rank 0 now holds every row
-            assert all(t.shape[0] == steps * B for t, _ in hosted)
-            return c16h, prh
-        c16, pr = stream.finish()
-        cdist.gather_rows([c16], dst=0)
-        cdist.gather_rows([pr], dst=0)
-        return None, None
+        done = push_host_frames(steps)
+        try:
+            if rank == 0:
+                c16h, prh = stream.finish_host()
+                g16 = cdist.gather_rows([torch.empty((0, cfg.hidden_size), dtype=torch.float16, device=device)], dst=0)
+                gpr = cdist.gather_rows([torch.empty((0, BEHAVIORS), dtype=torch.float32, device=device)], dst=0)
+                hosted = [(t[0].cpu(), u[0].cpu()) for t, u in zip(g16[1:], gpr[1:])]       # rank 0 now holds every row
+                assert all(t.shape[0] == steps * B for t, _ in hosted)
+                return c16h, prh
+            c16, pr = stream.finish()
+            cdist.gather_rows([c16], dst=0)
+            cdist.gather_rows([pr], dst=0)
+            torch.cuda.synchronize(device)            # the copies out of the page-locked ring have completed
+            return None, None
+        finally:
+            done()
 
     def timed_host():
         preroll(run_host_gathered)
@@ -416,8 +480,9 @@ def main() -> None:
     if not args.no_kernel_timing:
         torch.cuda.synchronize(device)
         enc.set_lanes(1)
+        preroll(run)                              # (outside the profile: its launches must not be counted into K steps' shares)
         enc.profile(True)
-        dt_events = timed()
+        dt_events = timed(pre=False)
         prof = enc.profile_read()
         enc.profile(False)
         enc.set_lanes(args.lanes)
@@ -467,8 +532,11 @@ def main() -> None:
         "dtype": {2: "fp8", 3: "f32"}.get(args.precision, "f16"), "data": "synthetic",
         "config": {"workload": f"DINOv3 ViT-{args.model[3:].upper()} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
                                f"batch={B}, chunked encode + BiLSTM head (C={BEHAVIORS}, seq_len={SEQ_LEN})",
-                   "input": ("uint8 RGB (n,H,W,3) in pinned host memory -> cbas_fused_push_u8_host (H2D on the copy stream, green "
-                             "picked on the device) -> encoder -> head -> fp16 CLS rows + fp32 probabilities in host memory"
+                   "input": ("uint8 RGB (n,H,W,3) in pinned host memory -> " +
+                             ("channel 1 kept by the decode-ahead thread while it fills page-locked ring pieces (cbas_pick_channel_u8) "
+                              "-> cbas_fused_push_u8_host (H2D of the green planes on the copy stream)" if args.host_input == "green" else
+                              "cbas_fused_push_u8_host (H2D of the RGB bytes on the copy stream, green picked on the device)") +
+                             " -> encoder -> head -> fp16 CLS rows + fp32 probabilities in host memory"
                              + (" of rank 0 (RCCL gather inside the timed region)" if world > 1 else "") +
                              ": SURVEY section 8(d)'s metric definition, PCIe inclusive (HBM-resident figure: hbm_resident)")
                             if dt_host is not None else
@@ -488,7 +556,8 @@ def main() -> None:
             "value": round(hbm_value, 2), "unit": "frames/s", "ms_per_step": round(dt / K * 1e3, 4),
             "what": "the same K steps with the uint8 frames already in HBM when the clock starts and the CLS rows / "
                     "probabilities left in HBM (gathered to rank 0's HBM with N > 1); no PCIe traffic in the timed region",
-            "h2d_bytes_per_frame_of_value": args.hw * args.hw * 3, "bit_identical_to_value_pass": host_equal}
+            "h2d_bytes_per_frame_of_value": args.hw * args.hw * (1 if args.host_input == "green" else 3),
+            "host_input_of_value": args.host_input, "bit_identical_to_value_pass": host_equal}
     if files is not None:
         out["files_path"] = files
     if not args.no_gates and not hung:

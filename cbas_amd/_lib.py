@@ -98,13 +98,14 @@ SIGNATURES = {
     "cbas_csv_format_f32": (c_int64, [c_void_p, c_int64, c_int32, c_void_p, c_int64]),
     "cbas_csv_write_f32": (c_int, [C.c_char_p, C.c_char_p, c_void_p, c_int64, c_int32, c_int32]),
     "cbas_mjpeg_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "cbas_pick_channel_u8": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32]),
     "cbas_last_error": (C.c_char_p, []),
     "cbas_abi_version": (c_int, []),
     "cbas_device_info": (c_int, [c_int, C.c_char_p, c_int, C.POINTER(c_int32), C.POINTER(c_int64)]),
 }
 
 ENC_SLOTS = 3
-EXPECTED_ABI = 8          # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
+EXPECTED_ABI = 9          # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
 PROF_CATS = ["patch_gemm", "layernorm", "qkv_gemm", "attention", "oproj_gemm", "up_gemm", "down_gemm", "other"]
 
 

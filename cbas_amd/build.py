@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libcbas_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["gemm_f16.hip", "gemm_f16_8ph.hip", "gemm_f16_skinny.hip", "gemm_f32.hip", "vit_f32.hip", "vit_kernels.hip", "head_kernels.hip", "head_train_kernels.hip",
-           "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip", "host_text.cpp", "host_mjpeg.cpp"]
+           "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip", "host_text.cpp", "host_mjpeg.cpp", "host_pixels.cpp"]
 EXTRA_FLAGS = {"host_mjpeg.cpp": ["-mavx2"]}      # host-only file: 8-lane integer vectors in the inverse DCT (checked at run time)
 ARCH = "gfx950"
 

@@ -436,6 +436,10 @@ bool Decoder::decode(const uint8_t* data, size_t size, int want_h, int want_w, i
                 const int pq = *s >> 4, tq = *s & 15;
                 ++s;
                 if (tq > 3 || pq > 1 || s + 64 * (pq + 1) > se) return fail("bad DQT segment");
+                // 16-bit tables (Pq = 1) belong to 12-bit JPEG; with 8-bit samples libjpeg accepts them, but entries up to
+                // 65 535 overflow the int32 arithmetic of fill_block / idct_block here (dc * quant * 4 + 16: undefined
+                // behaviour, and the vector products wrap differently from libjpeg's): hand such frames to the fallback
+                if (pq == 1) return fail("unsupported: 16-bit quantisation table");
                 for (int i = 0; i < 64; ++i) {
                     quant[tq][ZIGZAG[i]] = pq ? (uint16_t)((s[0] << 8) | s[1]) : s[0];
                     s += pq + 1;

@@ -611,6 +611,8 @@ class _FrameRange:
         if hasattr(reader, "frame_shape") and hasattr(reader, "read_into"):
             self.frame_shape = reader.frame_shape
             self.read_into = lambda i, j, out: reader.read_into(self._a + i, self._a + j, out)
+            if hasattr(reader, "read_channel_into"):
+                self.read_channel_into = lambda i, j, ch, out: reader.read_channel_into(self._a + i, self._a + j, ch, out)
 
     def __len__(self):
         return self._b - self._a

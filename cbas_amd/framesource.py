@@ -343,8 +343,7 @@ class MJPEGAviSource:
     def _decode(self, i: int) -> np.ndarray:
         import io
         from PIL import Image
-        while i > 0 and self._frames[i][1] == 0:
-            i -= 1
+        i = self._source_index(i)
         off, size = self._frames[i]
         with Image.open(io.BytesIO(self._mm[off:off + size])) as im:
             return np.asarray(im.convert("RGB"))
@@ -355,14 +354,29 @@ class MJPEGAviSource:
             self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix="cbas-mjpeg")
         return self._pool
 
+    def _source_index(self, i: int) -> int:
+        """The chunk that holds frame i's picture: a zero-length chunk (a dropped frame) stands for the frame before it;
+        zero-length chunks at the very START of the stream have no frame before them and show the first coded one."""
+        j = i
+        while j > 0 and self._frames[j][1] == 0:
+            j -= 1
+        if self._frames[j][1] == 0:                   # leading empty chunks
+            j = i
+            while j + 1 < len(self._frames) and self._frames[j][1] == 0:
+                j += 1
+        return j
+
     def _frame_table(self):
-        """(offsets, sizes) as the native decoder takes them; a zero-length chunk stands for the frame before it."""
+        """(offsets, sizes) as the native decoder takes them, empty chunks resolved as in ``_source_index``."""
         if self._table is None:
             off = np.array([f[0] for f in self._frames], np.uint64)
             size = np.array([f[1] for f in self._frames], np.uint32)
             src = np.arange(len(size))
             src[size == 0] = 0
             src = np.maximum.accumulate(src)          # index of the last non-empty chunk at or before each frame
+            coded = np.nonzero(size)[0]
+            if len(coded):
+                src[:coded[0]] = coded[0]             # leading empty chunks: the first coded frame
             self._table = (np.ascontiguousarray(off[src]), np.ascontiguousarray(size[src]))
         return self._table
 

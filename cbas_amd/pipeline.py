@@ -54,6 +54,11 @@ class NpyFrameSource:
 
     frame_shape = property(lambda self: tuple(self._a.shape[1:]))
 
+    def read_channel_into(self, start: int, stop: int, channel: int, out: np.ndarray) -> None:
+        """Channel ``channel`` of frames [start, stop) straight from the page cache into ``out`` (n,H,W) - a page-locked
+        ring piece: the native byte shuffle on a few threads (cbas_pick_channel_u8), one pass over the file's bytes."""
+        pick_channel(self._a[start:stop], channel, out)
+
     def read_into(self, start: int, stop: int, out: np.ndarray) -> None:
         """Frames [start, stop) straight from the page cache into ``out`` (a page-locked buffer): one copy, split over
         a few threads when it is large (numpy releases the GIL while it copies; one thread moves ~4 GB/s, and a GPU that
@@ -65,6 +70,16 @@ class NpyFrameSource:
         cuts = [start + (n * k) // 4 for k in range(5)]
         list(_copy_pool().map(lambda ab: np.copyto(out[ab[0] - start:ab[1] - start], self._a[ab[0]:ab[1]]),
                               zip(cuts[:-1], cuts[1:])))
+
+
+def pick_channel(frames: np.ndarray, channel: int, out: np.ndarray, threads: int = 4) -> None:
+    """out[n,H,W] = frames[n,H,W,C][..., channel] for C-contiguous uint8 frames (backend/cbas.py:431 keeps channel 1),
+    through the library's host helper (SSSE3 byte shuffle, threads)."""
+    assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.flags.c_contiguous, (frames.dtype, frames.shape)
+    assert out.dtype == np.uint8 and out.shape == frames.shape[:3] and out.flags.c_contiguous
+    lib = _lib.load()
+    _lib.check(lib.cbas_pick_channel_u8(frames.ctypes.data, int(np.prod(frames.shape[:3])), int(frames.shape[3]), int(channel),
+                                        out.ctypes.data, int(threads)), "cbas_pick_channel_u8")
 
 
 _COPY_POOL = None
@@ -527,14 +542,28 @@ class _ChunkStream:
         if shape is None or not hasattr(r, "read_into"):
             arr = r.get_batch(range(i, end))                     # learn the frame shape from the decoder's output
             shape = tuple(arr.shape[1:])
+        # Interleaved RGB (decord's layout, `.npy` clips): only channel 1 is consumed (backend/cbas.py:431), so only that
+        # plane is staged - a third of the page-locked bytes and of the host -> HBM copy (50 176 bytes
+        # per 224 x 224 frame).  CBAS_STAGE_GREEN=0 keeps the whole frame (the device picks the channel through its strides).
+        green = len(shape) == 3 and shape[2] == 3 and os.environ.get("CBAS_STAGE_GREEN") != "0" and \
+            (arr is None or (arr.dtype == np.uint8 and arr.flags.c_contiguous))
+        if green and arr is None and not hasattr(r, "read_channel_into"):
+            arr = r.get_batch(range(i, end))
+            green = arr.dtype == np.uint8 and arr.flags.c_contiguous
+        staged = tuple(shape[:2]) if green else tuple(shape)
         with self._ring_lock:
             if self._ring is None:
-                self._ring = _PinnedRing(self._piece * int(np.prod(shape)), depth=self._ring_depth)
+                self._ring = _PinnedRing(self._piece * int(np.prod(staged)), depth=self._ring_depth)
         k = self._ring.acquire(self._stop)
         if k is None:
             return None, None
-        out = self._ring.view(k, (end - i,) + tuple(shape))
-        if arr is None:
+        out = self._ring.view(k, (end - i,) + staged)
+        if green:
+            if arr is None:
+                r.read_channel_into(i, end, 1, out)
+            else:
+                pick_channel(arr, 1, out)
+        elif arr is None:
             r.read_into(i, end, out)
         else:
             np.copyto(out, arr)
@@ -911,6 +940,14 @@ class ClipRunner:
                 # while the caller removes the .tmp file.  abort() joins the thread; it is idempotent.
                 if pump is not None:
                     pump.abort()
+                # ... and must retire the batches this session still has in flight: they hold the ENCODER's slots, which the
+                # next clip's session (another one when the next call has a different head / temperature) submits to, and
+                # their host -> HBM copies read the page-locked ring that `closing(chunks)` is about to give back
+                if ent is not None:
+                    try:
+                        ent[0].reset()
+                    except Exception:  # noqa: BLE001 - the original error is the one to report
+                        pass
                 raise
         return res
 

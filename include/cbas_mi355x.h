@@ -51,7 +51,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   8
+#define CBAS_ABI_VERSION   9
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -394,6 +394,14 @@ int cbas_csv_write_f32(const char* path, const char* header_line, const float* v
 int cbas_mjpeg_decode(const uint8_t* data, const uint64_t* offsets, const uint32_t* sizes, int32_t n_frames,
                       int32_t height, int32_t width, int32_t channels, uint8_t* out, int32_t n_threads,
                       int32_t* bad_frame);
+
+/* ---- frame source: keep the consumed channel ---------------------------------------------------
+ * backend/cbas.py:431 keeps channel 1 of the decoded RGB frames (`frames_np[:, :, :, 1]`).  dst[i] = src[i * n_channels +
+ * channel] for n_pixels pixels (any number of frames back to back), on up to n_threads host threads: what the decode-ahead
+ * thread runs while it fills a page-locked ring piece, so that only the consumed plane is staged and copied to the device
+ * (50 176 bytes per 224 x 224 frame instead of 150 528).  Host memory in and out, no GPU involved. */
+int cbas_pick_channel_u8(const uint8_t* src, int64_t n_pixels, int32_t n_channels, int32_t channel, uint8_t* dst,
+                         int32_t n_threads);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 

@@ -322,3 +322,29 @@ def test_cloneable_readers_decode_on_several_instances(monkeypatch):
     next(iter(cs))
     cs.close()
     assert cs._ts == []
+
+
+# ---- green-only staging (r4) ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,channel", [((3, 7, 5, 3), 1), ((2, 224, 224, 3), 1), ((1, 1, 1, 3), 2), ((5, 33, 17, 4), 0),
+                                           ((40, 224, 224, 3), 1), ((2, 9, 9, 1), 0)])
+def test_pick_channel_native_equals_numpy(shape, channel):
+    """cbas_pick_channel_u8 (SSSE3 shuffle for 3 channels, plain loop otherwise, threads over pixel ranges) == numpy's
+    frames[..., channel] (backend/cbas.py:431 keeps channel 1), for sizes off every vector / thread boundary."""
+    from cbas_amd import pipeline as P
+    rng = np.random.default_rng(sum(shape))
+    fr = rng.integers(0, 256, shape, dtype=np.uint8)
+    for threads in (1, 3, 16):
+        out = np.full(shape[:3], 7, np.uint8)
+        P.pick_channel(fr, channel, out, threads=threads)
+        assert np.array_equal(out, fr[..., channel]), (shape, threads)
+
+
+def test_npy_source_reads_the_green_plane_directly(tmp_path):
+    from cbas_amd import pipeline as P
+    fr = np.random.default_rng(1).integers(0, 256, (70, 12, 20, 3), dtype=np.uint8)
+    p = str(tmp_path / "c.npy")
+    np.save(p, fr)
+    r = P.NpyFrameSource(p)
+    out = np.empty((30, 12, 20), np.uint8)
+    r.read_channel_into(25, 55, 1, out)
+    assert np.array_equal(out, fr[25:55, :, :, 1])

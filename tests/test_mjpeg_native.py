@@ -139,3 +139,66 @@ def test_threads_write_disjoint_frames(lib):
         rc, g, _bad, why = _decode(lib, blobs, 96, 96, 1, threads=t)
         assert rc == 0, why
         assert np.array_equal(g, ref), t
+
+
+def _to_16bit_dqt(blob: bytes) -> bytes:
+    """Rewrite every DQT segment of a baseline JPEG with 16-bit entries (Pq = 1): the same table values, legal JPEG."""
+    out, p = bytearray(blob[:2]), 2
+    while p < len(blob):
+        assert blob[p] == 0xFF
+        m = blob[p + 1]
+        if m == 0xDA:                                   # SOS: entropy data follows, copy the rest
+            out += blob[p:]
+            break
+        ln = (blob[p + 2] << 8) | blob[p + 3]
+        seg = blob[p + 4:p + 2 + ln]
+        if m == 0xDB:
+            body, s = bytearray(), 0
+            while s < len(seg):
+                pq, tq = seg[s] >> 4, seg[s] & 15
+                assert pq == 0
+                body.append(0x10 | tq)
+                for v in seg[s + 1:s + 65]:
+                    body += bytes([0, v])
+                s += 65
+            out += bytes([0xFF, 0xDB, (len(body) + 2) >> 8, (len(body) + 2) & 255]) + body
+        else:
+            out += blob[p:p + 2 + ln]
+        p += 2 + ln
+    return bytes(out)
+
+
+def test_16bit_quantisation_tables_go_to_the_fallback(lib, tmp_path):
+    """DQT tables with Pq = 1 (entries up to 65 535) would overflow the decoder's int32 arithmetic; they are
+    refused as "unsupported", so the reader hands such a stream to Pillow - and the frames still come out right."""
+    from cbas_amd import framesource as FS
+    rng = np.random.default_rng(12)
+    a = _picture(rng, 64, 64, "smooth")
+    good = _jpeg(a, quality=90)
+    wide = _to_16bit_dqt(good)
+    assert np.array_equal(_pillow(wide), _pillow(good))                  # still the same picture for libjpeg
+    rc, _o, bad, why = _decode(lib, [good, wide], 64, 64, 3)
+    assert rc != 0 and bad == 1 and "unsupported: 16-bit quantisation table" in why
+
+
+def test_avi_with_leading_and_inner_empty_chunks(tmp_path):
+    """A zero-length '00dc' chunk is a dropped frame: it shows the frame before it; at the very start of the stream it
+    shows the first coded frame (it used to map to itself and be reported as a corrupt stream)."""
+    from cbas_amd import framesource as FS
+    rng = np.random.default_rng(13)
+    frames = np.stack([_picture(rng, 48, 64, "smooth") for _ in range(5)])
+    p = str(tmp_path / "c.avi")
+    FS.write_mjpeg_avi(p, frames, quality=92)
+    src = FS.MJPEGAviSource(p)
+    want = src.get_batch(range(5)).copy()
+    # drop frames 0, 1 and 3 by zeroing their sizes in the reader's table (what an index with empty chunks parses to)
+    for k in (0, 1, 3):
+        src._frames[k] = (src._frames[k][0], 0)
+    src._table = None
+    got = src.get_batch(range(5))
+    assert np.array_equal(got[0], want[2]) and np.array_equal(got[1], want[2]) and np.array_equal(got[2], want[2])
+    assert np.array_equal(got[3], want[2]) and np.array_equal(got[4], want[4])
+    src._native = False                                                  # the Pillow path resolves them the same way
+    got2 = src.get_batch(range(5))
+    assert np.array_equal(got2, got)
+    src.close() if hasattr(src, "close") else None
