@@ -121,6 +121,11 @@ def test_encode_infer_file_equals_encode_file_then_infer_file(tmp_path):
                 if start >= 1024:
                     raise IOError("decode failed at 1024")
                 super().read_into(start, stop, out)
+
+            def read_channel_into(self, start, stop, channel, out):      # r4: the ring is filled with the green plane only
+                if start >= 1024:
+                    raise IOError("decode failed at 1024")
+                super().read_channel_into(start, stop, channel, out)
         with pytest.raises(IOError, match="1024"):
             P.encode_infer_file(enc, head, str(tmp_path / "b3" / "v.npy"), "zz", names, reader=Breaks(str(tmp_path / "b3" / "v.npy")))
         assert not os.path.exists(str(tmp_path / "b3" / "v_zz_outputs.csv"))
