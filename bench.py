@@ -584,15 +584,17 @@ def main() -> None:
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                               "share": round(v["ms"] * 1e-3 / dt_events, 4)} for k, v in prof.items()},
         }
-        pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
-        # the committed PMC passes were taken on the headline workload only; other workloads report null
-        if os.path.exists(pmc) and (args.model, args.hw, B, args.precision) == ("vitb16", 224, 64, 0):
+        # the committed PMC passes cover the headline workload in its default and fp32 modes; other workloads report null
+        pmc_file, pmc_key, pmc_cmd = {0: ("pmc_traffic.json", "gemm_f16_hbm_bytes_per_launch", "scripts/quick_perf.py vitb16 64 3"),
+                                      3: ("r04_pmc_traffic_fp32.json", "gemm_f32_hbm_bytes_per_launch",
+                                          "scripts/quick_perf.py vitb16 64 3 224 3")}.get(args.precision, (None, None, None))
+        pmc = os.path.join(HERE, "profiles", pmc_file) if pmc_file else None
+        if pmc and os.path.exists(pmc) and (args.model, args.hw, B) == ("vitb16", 224, 64):
             try:
-                out["roofline"]["traffic"] = json.load(open(pmc)).get("gemm_f16_hbm_bytes_per_launch")
-                out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                     "passes over scripts/quick_perf.py vitb16 64 3 - the same encoder, batch and "
-                                                     "kernels as this command, frames resident (scripts/profile_round.sh); not "
-                                                     "measured in this run")
+                out["roofline"]["traffic"] = json.load(open(pmc)).get(pmc_key)
+                out["roofline"]["traffic_source"] = (f"profiles/{pmc_file}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                                     f"{pmc_cmd} - the same encoder, batch and kernels as this command, frames "
+                                                     "resident (scripts/profile_round.sh, scripts/profile_r04.sh); not measured in this run")
             except Exception:  # noqa: BLE001
                 pass
     if world == 1 and not args.no_cpu_baseline and not hung:
