@@ -206,3 +206,75 @@ def test_fp32_e2e_long_clip_labels_identical(golden_dir):
         pytest.skip("long fixture not generated")
     g, cls16, probs = _e2e(golden_dir, "e2e_vitb16_long", C.VIT_B16, 768, 64)
     _strict_gate(golden_dir, "fp32 e2e_vitb16_long", "e2e_vitb16_long", g, cls16, probs, g["cls_every8"], slice(0, None, 8))
+
+
+def test_fp32_dinov2_with_registers(golden_dir):
+    """CBAS's default encoder family in precision 3 (patch 14, interpolated position embedding, key bias, no RoPE, LN eps
+    1e-6): the tiny model's embeddings (incl. the bicubic-antialias interpolation) and CLS at three frame sizes, ViT-B/14 at
+    224 and 256 against HF Dinov2WithRegistersModel / the reference's own wrapper - to fp32 rounding."""
+    from cbas_amd.encoder import DinoEncoder
+    g = load(golden_dir, "dinov2reg_tiny")
+    cfg = C.DINOV2_REG_TINY
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(84, 84), precision=3)
+    try:
+        for hw in (70, 56, 84, 70):
+            fr = synth.cage_frames(20 + hw, 3, hw, hw)
+            fd = torch.from_numpy(fr).cuda()
+            emb = enc.debug_tap(fd, 0, 0, 0).reshape(3, -1, cfg.hidden_size)
+            assert np.abs(emb - g[f"emb_{hw}"]).max() < 2e-5
+            _, c32 = enc.encode_u8(fd)
+            torch.cuda.synchronize()
+            r = rel_rows(c32.cpu().numpy(), g[f"last_{hw}"][:, 0])
+            assert r.max() < CLS_TOL_F32, (hw, r.max())
+    finally:
+        enc.close()
+    g = load(golden_dir, "dinov2reg_b14")
+    cfg = C.DINOV2_REG_B14
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(256, 256), precision=3)
+    try:
+        for hw, seed, n in ((224, 31, 4), (256, 32, 2)):
+            fr = synth.cage_frames(seed, n, hw, hw)
+            _, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+            torch.cuda.synchronize()
+            r = rel_rows(c32.cpu().numpy(), g[f"cls{hw}"])
+            print(f"[fp32 dinov2reg_b14 {hw}] CLS rel err max {r.max():.3e}")
+            assert r.max() < CLS_TOL_F32, (hw, r.max())
+    finally:
+        enc.close()
+
+
+def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, tmp_path):
+    """encode_file / infer_file / encode_infer_file with a precision-3 encoder, against the `_cls.h5` rows the REFERENCE's
+    own encode_file wrote for the same 600-frame 'video' (tests/golden/encode_file_b1layer.npz): the fp16 rows are the
+    reference's except where a value sits on a rounding boundary (well under 1 % of the elements, one ulp each) - the
+    fp16-operand default differs in ~2/3 of the elements - and the two file paths agree byte for byte."""
+    from cbas_amd import pipeline as P, h5io
+    from cbas_amd.encoder import DinoEncoder
+    g = load(golden_dir, "encode_file_b1layer")
+    cfg = C.ViTConfig(hidden_size=768, intermediate_size=1536, num_hidden_layers=1, num_attention_heads=12, image_size=32)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(32, 32), precision=3)
+    head = make_head(768)
+    try:
+        frames = synth.cage_frames(5, 600, 32, 32)
+        a, b = tmp_path / "a", tmp_path / "b"
+        a.mkdir(); b.mkdir()
+        np.save(str(a / "vid.npy"), frames)
+        np.save(str(b / "vid.npy"), frames)
+        ticks = []
+        out = P.encode_file(enc, str(a / "vid.npy"), progress_callback=ticks.append)
+        np.testing.assert_allclose(ticks, g["ticks"])
+        with h5io.ClsReader(out) as r:
+            got = r.read(0, 600)
+        ref = g["cls_f16"]
+        diff = got != ref
+        # one fp16 ulp, or - for elements near zero, where an fp16 ulp is far below fp32's own noise on an O(1) row - 4e-6
+        one_ulp = np.abs(got.astype(np.float32) - ref.astype(np.float32))[diff] <= np.abs(ref.astype(np.float32))[diff] * 2.0 ** -10 + 4e-6
+        print(f"[fp32 encode_file] {diff.mean() * 100:.3f} % of the fp16 elements differ from the reference's file, all by one ulp "
+              f"(or the fp32 noise floor near zero): {bool(one_ulp.all())}")
+        assert diff.mean() < 1e-2 and one_ulp.all()
+        names = ["eating", "drinking", "rearing", "climbing", "digging", "nesting", "resting", "grooming", "exploring"]
+        csv = P.infer_file(out, head, "ds", names, 31, device="cuda")
+        h5b, csvb = P.encode_infer_file(enc, head, str(b / "vid.npy"), "ds", names)
+        assert open(out, "rb").read() == open(h5b, "rb").read() and open(csv, "rb").read() == open(csvb, "rb").read()
+    finally:
+        enc.close(); head.close()
