@@ -224,7 +224,7 @@ def _p2p(op, tensor: torch.Tensor, peer: int):
 
 def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optional[str] = None,
                  behaviors: Optional[Sequence[str]] = None, temperature: float = 1.0,
-                 progress_callback=None, csv_threads: int = 2) -> Optional[List[dict]]:
+                 progress_callback=None, csv_threads: int = 2, local_writes: bool = False) -> Optional[List[dict]]:
     """Drain a list of videos on all ranks: what the reference's EncodeThread queue (+ ClassificationThread when a model
     is live) does on one device (backend/workthreads.py:276-348, 453-519), sharded by clip over one process per GPU.
 
@@ -240,6 +240,12 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     * **Files.**  The receiver hands the rows to ``_OutputWriter`` (one HDF5 thread + a CSV pool); rank 0's own encode loop
       never writes.  Files are what ``encode_file`` / ``infer_file`` write, byte for byte (``.tmp`` + rename, encoder
       stamp, CSV header = behaviours), whatever rank encoded them and in whatever order they completed.
+
+    ``local_writes=True`` (one node, one filesystem): every rank writes the files of ITS clips with its own writer threads
+    and only a status ticket goes to rank 0 - no rows cross xGMI and no rank's files queue behind another's.  The gather is
+    the default because it is what the path's specification asks for; it costs a tail when there is about one clip per GPU:
+    all clips end together and their `_cls.h5` writes (22 ms per 18 000-frame clip) queue on rank 0's one HDF5 thread -
+    8 x 22 ms after a 0.81 s encode at BASELINE configs[2] (tests/test_dist_encode_files.py, the world-8 rehearsal).
 
     A clip that fails on its rank is logged there and skipped, as EncodeThread does (workthreads.py:334-336); a video
     without frames yields no file.  Returns on rank 0 one record per clip, in clip order, {"path", "frames", "cls_file",
@@ -287,9 +293,11 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     writer = receiver = None
     local_done: dict = {}                                  # rank 0's own clips: clip -> (rows, probs) host arrays
     recv_err: list = []
-    if rank == 0:
+    lw = bool(local_writes) and world > 1                  # every rank writes its own clips' files
+    if rank == 0 or lw:
         writer = _OutputWriter(records, dataset_name if head is not None else None, behaviors, P.file_attrs(encoder),
                                csv_threads)
+    if rank == 0:
 
         def take(t: dict):
             clip, src, n = t["clip"], t["rank"], t["n"]
@@ -297,6 +305,9 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             rec["rank"] = src
             rec["status"] = {_ST_OK: "ok", _ST_EMPTY: "empty", _ST_FAILED: "failed"}[t["status"]]
             if t["status"] != _ST_OK:
+                return
+            if t.get("local") and src != 0:                # written by its own rank (local_writes): the outcome follows
+                rec["frames"] = int(n)
                 return
             if src == 0:
                 rows, probs = local_done.pop(clip)
@@ -358,7 +369,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
 
     def publish(clip: int, status: int, n: int, has_probs: bool):
         published.add(clip)
-        t = {"rank": rank, "clip": clip, "status": status, "n": int(n), "probs": bool(has_probs)}
+        t = {"rank": rank, "clip": clip, "status": status, "n": int(n), "probs": bool(has_probs), "local": lw}
         if store is None:
             tickets[f"{prefix}t{clip_seq[0]}"] = t
             clip_seq[0] += 1
@@ -382,6 +393,13 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             local_done[clip] = (rows, probs)
             publish(clip, _ST_OK, n, has_probs)
             return
+        if lw:                                             # this rank's own writer threads take the clip
+            rows = res.rows.cpu().numpy() if res.on_device else res.rows
+            probs = (res.probs.cpu().numpy() if res.on_device else res.probs) if has_probs else None
+            records[clip]["rank"], records[clip]["status"] = rank, "ok"
+            writer.submit(clip, rows, probs)
+            publish(clip, _ST_OK, n, has_probs)
+            return
         publish(clip, _ST_OK, n, has_probs)
         if n:
             rows = res.rows if nccl else torch.from_numpy(res.rows) if not res.on_device else res.rows.cpu()
@@ -398,7 +416,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     # before clip i's tail - its last batches, the tail classification, the copy-out - is waited for, so the GPU never idles
     # between clips (a clip's fixed cost was ~8 ms: 10 % of a 2 048-frame clip).  On RCCL ranks > 0 the rows leave from
     # the session's device buffers instead (two sessions alternate there already).
-    pipelined = not (nccl and rank != 0)
+    pipelined = lw or not (nccl and rank != 0)
     if pipelined and runner.native and len(runner._sessions) < 2:
         runner._sessions.append(None)
     prev = None                                            # (clip, pending result) of the clip before the current one
@@ -482,6 +500,14 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 publish(c, _ST_FAILED, 0, False)
             except Exception:  # noqa: BLE001
                 pass
+        if lw and rank != 0:
+            # local_writes: wait for this rank's files, then tell rank 0 how each of its clips ended (before `left`)
+            try:
+                writer.close()
+                mine = {str(c): [r["status"], r["cls_file"], r["csv_file"], r["frames"]] for c, r in enumerate(records) if r["rank"] == rank}
+                store.set(f"{prefix}written{rank}", json.dumps(mine))
+            except Exception as e:  # noqa: BLE001
+                print(f"ERROR closing the writers of rank {rank}: {e}")
         if store is not None:
             hb_stop.set()
             try:
@@ -493,6 +519,25 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 stop.set()                                 # an error is on its way up and nobody else can publish: do not wait
             receiver.join()
             writer.close()
+            if lw:
+                # the other ranks' outcomes: each publishes `written<r>` before `left<r>`; a rank that is gone without it
+                # leaves its clips "failed"
+                for r in range(1, world):
+                    t_wait = 0.0
+                    while not store.check([f"{prefix}written{r}"]):
+                        if store.check([f"{prefix}left{r}"]) and not store.check([f"{prefix}written{r}"]):
+                            break
+                        if store.check([f"{prefix}hb{r}"]) and time.time() - float(store.get(f"{prefix}hb{r}").decode()) > dead_after:
+                            break
+                        time.sleep(0.002)
+                        t_wait += 0.002
+                    got = json.loads(store.get(f"{prefix}written{r}").decode()) if store.check([f"{prefix}written{r}"]) else {}
+                    for c, rec in enumerate(records):
+                        if rec["rank"] == r and rec["status"] == "ok":
+                            st_, h5_, csv_, fr_ = got.get(str(c), ["failed", None, None, 0])
+                            rec["status"], rec["cls_file"], rec["csv_file"] = st_, h5_, csv_
+                            if st_ != "ok":
+                                rec["cls_file"] = rec["csv_file"] = None
         runner.close()
     if recv_err:
         raise recv_err[0]

@@ -53,6 +53,9 @@ def main(argv=None) -> int:
     ap.add_argument("--split-clips", choices=("auto", "always", "never"), default="auto",
                     help="split EACH video's frames over all GPUs (halo exchange at the cuts) instead of giving each GPU "
                          "whole videos; auto: when there are fewer videos than GPUs")
+    ap.add_argument("--local-writes", action="store_true",
+                    help="every rank writes the files of its own videos (one node, one filesystem) instead of sending the rows "
+                         "to rank 0: no write queue on rank 0 when there is about one video per GPU")
     ap.add_argument("--max-batch", type=int, default=128)
     ap.add_argument("--max-frame", type=int, nargs=2, default=(256, 256))
     ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2, 3),
@@ -112,7 +115,7 @@ def main(argv=None) -> int:
             print(f"{ok} of {len(videos)} videos encoded, each split over {world} GPU(s)")
     else:
         recs = cdist.encode_files(videos, enc, head=head, dataset_name=name, behaviors=hp.get("behaviors"),
-                                  temperature=temperature)
+                                  temperature=temperature, local_writes=args.local_writes)
         cdist.barrier()
         if rank == 0:
             ok = sum(r["status"] == "ok" for r in recs)

@@ -98,12 +98,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, td, q):
+def _worker(rank, world, port, td, q, local_writes=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     cdist.init_from_env("gloo")
     P.set_project_stamp("facebook/dinov3-vitb16-pretrain-lvd1689m")
     paths = sorted(p for p in (os.path.join(td, f) for f in os.listdir(td)) if p.endswith(".npy"))
-    recs = cdist.encode_files(paths, StubEncoder(), head=StubHead(), dataset_name="gold", behaviors=NAMES, temperature=0.9)
+    recs = cdist.encode_files(paths, StubEncoder(), head=StubHead(), dataset_name="gold", behaviors=NAMES, temperature=0.9,
+                              local_writes=local_writes)
     if rank == 0:
         q.put(recs)
     else:
@@ -112,8 +113,8 @@ def _worker(rank, world, port, td, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_encode_files_matches_single_process_byte_for_byte(tmp_path, world):
+@pytest.mark.parametrize("world,local_writes", [(2, False), (3, False), (3, True)])
+def test_encode_files_matches_single_process_byte_for_byte(tmp_path, world, local_writes):
     ref_dir, run_dir = str(tmp_path / "ref"), str(tmp_path / "run")
     os.makedirs(ref_dir)
     os.makedirs(run_dir)
@@ -141,7 +142,7 @@ def test_encode_files_matches_single_process_byte_for_byte(tmp_path, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, run_dir, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, run_dir, q, local_writes)) for r in range(world)]
     for p in procs:
         p.start()
     recs = q.get(timeout=180)
@@ -194,7 +195,7 @@ class LatencyHead(StubHead):
         probs_out[first:first + count] = torch.softmax(cls_rows[first:first + count, :C_].float() * 4.0 / max(1e-3, temperature), dim=1)
 
 
-def _timed_worker(rank, world, port, td, q, per_frame, write_s, head_s=None):
+def _timed_worker(rank, world, port, td, q, per_frame, write_s, head_s=None, local_writes=False):
     import time
     torch.set_num_threads(1)                               # ranks share this container's 8 cores: no oversubscription
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -210,7 +211,7 @@ def _timed_worker(rank, world, port, td, q, per_frame, write_s, head_s=None):
     enc, head = LatencyEncoder(per_frame), (StubHead() if head_s is None else LatencyHead(head_s))
     cdist.barrier()
     t0 = time.perf_counter()
-    recs = cdist.encode_files(paths, enc, head=head, dataset_name="gold", behaviors=NAMES)
+    recs = cdist.encode_files(paths, enc, head=head, dataset_name="gold", behaviors=NAMES, local_writes=local_writes)
     cdist.barrier()
     wall = time.perf_counter() - t0
     if rank == 0:
@@ -220,7 +221,7 @@ def _timed_worker(rank, world, port, td, q, per_frame, write_s, head_s=None):
         dist.destroy_process_group()
 
 
-def _run_timed(tmp_path, world, lengths, per_frame, write_s, head_s=None):
+def _run_timed(tmp_path, world, lengths, per_frame, write_s, head_s=None, local_writes=False):
     td = str(tmp_path)
     os.makedirs(td, exist_ok=True)
     rng = np.random.default_rng(3)
@@ -229,7 +230,7 @@ def _run_timed(tmp_path, world, lengths, per_frame, write_s, head_s=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, td, q, per_frame, write_s, head_s)) for r in range(world)]
+    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, td, q, per_frame, write_s, head_s, local_writes)) for r in range(world)]
     for p in procs:
         p.start()
     wall, recs = q.get(timeout=240)
@@ -491,3 +492,9 @@ def test_cfg3_rehearsal_eight_ranks_one_18000_frame_clip_each(tmp_path):
     assert sum(r["frames"] for r in recs) == 8 * n
     assert wall <= one + 8 * write_s + 0.35            # encode + the eight serial writes + process noise of this container
     assert 8 * n / wall >= 5.0 * (n / one)             # at least 5 x one rank's rate even in this worst case for the tail
+    # the same job with every rank writing its own clip's files (encode_files(local_writes=True)): no queue on rank 0
+    wall_l, recs_l = _run_timed(tmp_path / "eight_local", 8, [n] * 8, per_frame=per_frame, write_s=write_s, head_s=0.016,
+                                local_writes=True)
+    print(f"cfg3 rehearsal, local writes: {wall_l:.3f} s = {wall_l / one:.3f} x the single-rank clip ({8 * n / wall_l / (n / one):.2f} x of 8)")
+    assert sorted(r["rank"] for r in recs_l) == list(range(8)) and sum(r["frames"] for r in recs_l) == 8 * n
+    assert wall_l <= 1.15 * one + 0.15                 # the verdict's bound (+ this container's process noise)

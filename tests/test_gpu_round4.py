@@ -305,3 +305,68 @@ def test_cfg5_fp8_batch_128(golden_dir):
     print(f"[cfg5 batch 128] CLS rel err: GPU vs MX restatement {r_emu:.3e} | GPU vs fp32 reference {r_ref:.3e} | restatement vs "
           f"reference {r_emu_ref:.3e}")
     assert r_emu < 8e-2 and r_ref < 1.0e-1 and r_ref < 1.5 * r_emu_ref + 1e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# encode_files(local_writes=True): every rank writes its own clips' files
+# ------------------------------------------------------------------------------------------------------------------
+def _local_writes_rank(rank, world, port, td, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from cbas_amd import dist as cdist, pipeline as P
+    cdist.init_from_env("gloo")
+    cfg, enc, head = _tiny_pair()
+    P.set_project_stamp("enc-id")
+    paths = [os.path.join(td, f"v{i}.npy") for i in range(5)]
+    recs = cdist.encode_files(paths, enc, head=head, dataset_name="ds", behaviors=NAMES, temperature=0.7, local_writes=True)
+    if rank == 0:
+        q.put(recs)
+    dist.barrier()
+    head.close(); enc.close()
+    dist.destroy_process_group()
+
+
+def test_encode_files_local_writes_two_ranks_real_kernels(tmp_path):
+    """Two gloo ranks on the real kernels, each writing the files of the clips it encoded: the same bytes as the
+    single-process encode_file / infer_file, records assembled on rank 0 from the ranks' outcome reports."""
+    import hashlib, shutil, socket
+    import torch.multiprocessing as mp
+    from cbas_amd import pipeline as P
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()          # noqa: E731
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    for i, n in enumerate((50, 0, 530, 31, 64)):
+        np.save(str(a / f"v{i}.npy"), synth.cage_frames(70 + i, n, 64, 64))
+        shutil.copy(str(a / f"v{i}.npy"), str(b / f"v{i}.npy"))
+    cfg, enc, head = _tiny_pair()
+    P.set_project_stamp("enc-id")
+    exp = []
+    try:
+        for i in range(5):
+            h5 = P.encode_file(enc, str(a / f"v{i}.npy"))
+            exp.append(None if h5 is None else (sha(h5), sha(P.infer_file(h5, head, "ds", NAMES, 31, device="cuda", temperature=0.7))))
+    finally:
+        P.set_project_stamp(None)
+        head.close(); enc.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_local_writes_rank, args=(r, 2, port, str(b), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        recs = q.get(timeout=240)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+    assert [r["status"] for r in recs] == ["ok", "empty", "ok", "ok", "ok"]
+    assert {r["rank"] for r in recs if r["status"] == "ok"} <= {0, 1}
+    for r, e in zip(recs, exp):
+        if e is not None:
+            assert (sha(r["cls_file"]), sha(r["csv_file"])) == e, r["path"]
