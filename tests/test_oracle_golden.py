@@ -52,9 +52,16 @@ def test_vit_cls_goldens(golden_dir, name, cfgname, hw):
     mk = synth.noise_frames if str(g["kind"]) == "noise" else synth.cage_frames
     fr = mk(int(g["frame_seed"]), n, hw, hw)
     assert sha(fr) == str(g["frames_sha"])
-    cls = PO.encode_frames(fr, w, cfg, batch=4)
-    rel = np.linalg.norm(cls - g["cls"], axis=1) / np.linalg.norm(g["cls"], axis=1)
+    # the numpy restatement on the first frames (ViT-B: ~4 s per frame), the torch restatement of the same arithmetic on
+    # all of them: the CPU suite has to stay within a few minutes
+    k = min(n, 2 if cfgname == "vitb16" else 4)
+    cls = PO.encode_frames(fr[:k], w, cfg, batch=4)
+    rel = np.linalg.norm(cls - g["cls"][:k], axis=1) / np.linalg.norm(g["cls"][:k], axis=1)
     assert rel.max() < 1e-5, rel.max()
+    from oracle import vit_oracle_torch as VT
+    cls_t = VT.encode_frames(fr, VT.to_torch(w), cfg, batch=4)
+    rel_t = np.linalg.norm(cls_t - g["cls"], axis=1) / np.linalg.norm(g["cls"], axis=1)
+    assert rel_t.max() < 1e-5, rel_t.max()
 
 
 @pytest.mark.slow
@@ -66,10 +73,10 @@ def test_vitl_cls_goldens(golden_dir, name, hw):
     n = int(g["n"])
     fr = synth.cage_frames(int(g["frame_seed"]), n, hw, hw)
     assert sha(fr) == str(g["frames_sha"])
-    k = 1 if hw > 256 else 2                       # numpy ViT-L: ~20 s per 224x224 frame, ~55 s per 518x518 frame
-    cls = PO.encode_frames(fr[:k], w, cfg, batch=1)
-    rel = np.linalg.norm(cls - g["cls"][:k], axis=1) / np.linalg.norm(g["cls"][:k], axis=1)
-    assert rel.max() < 2e-5, rel.max()
+    if hw <= 256:                                  # numpy ViT-L: ~20 s per 224x224 frame, ~55 s per 518x518 frame: one small one
+        cls = PO.encode_frames(fr[:1], w, cfg, batch=1)
+        rel = np.linalg.norm(cls - g["cls"][:1], axis=1) / np.linalg.norm(g["cls"][:1], axis=1)
+        assert rel.max() < 2e-5, rel.max()
     # every golden frame through the torch restatement of the same arithmetic (oracle/vit_oracle_torch.py)
     from oracle import vit_oracle_torch as VT
     cls_t = VT.encode_frames(fr, VT.to_torch(w), cfg, batch=2)
@@ -143,10 +150,10 @@ def test_e2e_config1_golden(golden_dir):
     assert sha(fr) == str(g["frames_sha"])
     enc_w = W.synth_encoder_weights(cfg, 1234)
     head_w = W.synth_head_weights(C.HeadConfig(in_features=384), 4321)
-    # the numpy restatement on the first two batches of 8, the torch restatement of the same arithmetic on all 64 frames
+    # the numpy restatement on the first batch of 8, the torch restatement of the same arithmetic on all 64 frames
     # (numpy ViT-S: ~2 s per frame)
-    first = PO.encode_frames(fr[:16], enc_w, cfg, batch=8)
-    rel16 = np.linalg.norm(first - g["cls"][:16], axis=1) / np.linalg.norm(g["cls"][:16], axis=1)
+    first = PO.encode_frames(fr[:8], enc_w, cfg, batch=8)
+    rel16 = np.linalg.norm(first - g["cls"][:8], axis=1) / np.linalg.norm(g["cls"][:8], axis=1)
     assert rel16.max() < 1e-5
     from oracle import vit_oracle_torch as VT
     cls32 = VT.encode_frames(fr, VT.to_torch(enc_w), cfg, batch=8)
