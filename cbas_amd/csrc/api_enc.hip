@@ -43,6 +43,8 @@ struct LayerW {
     float *qkv_cs = nullptr, *qkv_bf = nullptr, *up_cs = nullptr, *up_bf = nullptr;
     // precision 3: the fp32 weights themselves ([N][K] as stored in the blob; q | k | v packed into one [3D][D] copy)
     const float *wqkv32 = nullptr, *wo32 = nullptr, *wup32 = nullptr, *wdown32 = nullptr;
+    // precision 4: power-of-two scale per weight tensor that brings max |w| into [1, 2) before the fp16 split
+    float sc_qkv = 1.f, sc_o = 1.f, sc_up = 1.f, sc_down = 1.f;
 };
 
 struct Slot {
@@ -73,8 +75,9 @@ struct cbas_enc {
     uint32_t* w8_sc = nullptr;                 //              and their block scales
     uint32_t *sc_h = nullptr, *sc_u = nullptr; // precision 2: block scales of the fp8 activations in h16 / u16 ([K/128][rows_cap])
     f16 *wpatch, *wpatch2, *wpatch_lo, *wpatch2_lo;
-    float* w32 = nullptr;                      // precision 3: packed q|k|v weights of every layer + the (D,256) patch weight
+    float* w32 = nullptr;                      // precision 3 / 4: packed q|k|v weights of every layer + the (D,256) patch weight
     const float* wpatch32 = nullptr;
+    float sc_patch = 1.f;                      // precision 4: scale of the patch weight (see LayerW)
     float* qkv_bias_all = nullptr;
     float* prefix_dev = nullptr;        // (1+R, D): cls (+ its position embedding for DINOv2) | registers
     float* pos_tab = nullptr;           // DINOv2: (Pmax, D) position embedding interpolated to the current grid
@@ -398,7 +401,13 @@ int run_blocks_f32(cbas_enc* h, int n, int height, int width, float* cls_f32, f1
     float* const u32 = reinterpret_cast<float*>(h->u16);
     const float eps = h->cfg.layer_norm_eps;
 
+    // precision 4: the same schedule with every GEMM's products on the fp16 pipe as three-term splits; operand scales:
+    // LayerNorm rows and pixels as they are, attention context x 16, GELU output x 4 (typical magnitudes ~0.05 / ~0.3:
+    // keeps their low halves out of fp16's subnormal range), weights by their per-tensor power of two
+    const int split = h->cfg.precision == 4;
+    auto sp = [&](Gemm32VitParams& q, float a_scale, float w_scale) { q.split = split; q.a_scale = a_scale; q.w_scale = w_scale; };
     Gemm32VitParams g{};
+    sp(g, 1.f, h->sc_patch);
     g.A = A32; g.lda = 256; g.W = h->wpatch32; g.M = n * P; g.N = D; g.K = 256; g.bias = h->patch_b; g.out = h->x; g.ldo = D;
     g.patches_per_frame = P; g.tokens_per_frame = T; g.n_prefix = h->NP; g.pos = h->cfg.use_rope ? nullptr : h->pos_tab;
     { PROF(CBAS_PROF_PATCH, 2.0 * g.M * g.N * g.K); LAUNCH_TRY(launch_gemm_f32_vit(EPI_PATCH, g, st)); }
@@ -420,50 +429,61 @@ int run_blocks_f32(cbas_enc* h, int n, int height, int width, float* cls_f32, f1
             float* cc = qc + cap * D;                            // [n][D] attention context
             float* hc = cc + cap * D;                            // [n][D] LayerNorm rows
             float* uc = hc + cap * D;                            // [n][F] GELU(up_proj)
-            { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln1_w, w.ln1_b, h32, M, D, eps, st)); }
+            { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln1_w, w.ln1_b, h32, M, D, eps, split, st)); }
             Gemm32VitParams kv{};
             qkv_params(w, kv);
+            sp(kv, 1.f, w.sc_qkv);
             kv.A = h32; kv.lda = D; kv.W = w.wqkv32 + (size_t)D * D; kv.M = M; kv.N = 2 * D; kv.bias = w.qkv_b + D;
             kv.out = qkv32 + D; kv.ldo = 3 * D; kv.sec0 = 1;
             { PROF(CBAS_PROF_QKV, 2.0 * M * 2.0 * D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_QKV, kv, st)); }
             Gemm32VitParams q{};
             qkv_params(w, q);
+            sp(q, 1.f, w.sc_qkv);
             q.A = h32; q.lda = (int64_t)T * D; q.W = w.wqkv32; q.M = n; q.N = D; q.bias = w.qkv_b; q.out = qc; q.ldo = D;
             q.tokens_per_frame = 1; q.n_prefix = 1; q.sec0 = 0;       // every row is token 0: no RoPE
             { PROF(CBAS_PROF_QKV, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_QKV, q, st)); }
-            { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * D); LAUNCH_TRY(launch_attention_f32(qkv32, qc, cc, n, T, D, h->NH, st)); }
+            { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * D); LAUNCH_TRY(launch_attention_f32(qkv32, qc, cc, n, T, D, h->NH, split ? 16.f : 0.f, st)); }
             Gemm32VitParams o{};
+            sp(o, 16.f, w.sc_o);
             o.A = cc; o.lda = D; o.W = w.wo32; o.M = n; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out = h->x; o.ldo = (int64_t)T * D;
             { PROF(CBAS_PROF_OPROJ, 2.0 * n * (double)D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, o, st)); }
-            { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, (int64_t)T * D, w.ln2_w, w.ln2_b, hc, n, D, eps, st)); }
+            { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, (int64_t)T * D, w.ln2_w, w.ln2_b, hc, n, D, eps, split, st)); }
             Gemm32VitParams u{};
+            sp(u, 1.f, w.sc_up);
+            u.out_scale = 4.f;
             u.A = hc; u.lda = D; u.W = w.wup32; u.M = n; u.N = F; u.K = D; u.bias = w.up_b; u.out = uc; u.ldo = F;
             { PROF(CBAS_PROF_UP, 2.0 * n * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_GELU, u, st)); }
             Gemm32VitParams d{};
+            sp(d, 4.f, w.sc_down);
             d.A = uc; d.lda = F; d.W = w.wdown32; d.M = n; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out = h->x; d.ldo = (int64_t)T * D;
             { PROF(CBAS_PROF_DOWN, 2.0 * n * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, d, st)); }
             break;
         }
-        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln1_w, w.ln1_b, h32, M, D, eps, st)); }
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln1_w, w.ln1_b, h32, M, D, eps, split, st)); }
         if (stop(1)) return CBAS_OK;
         Gemm32VitParams q{};
         qkv_params(w, q);
+        sp(q, 1.f, w.sc_qkv);
         q.A = h32; q.lda = D; q.W = w.wqkv32; q.M = M; q.N = 3 * D; q.bias = w.qkv_b; q.out = qkv32; q.ldo = 3 * D;
         { PROF(CBAS_PROF_QKV, 2.0 * M * 3.0 * D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_QKV, q, st)); }
         if (stop(2)) return CBAS_OK;
-        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention_f32(qkv32, nullptr, h32, n, T, D, h->NH, st)); }
+        { PROF(CBAS_PROF_ATTENTION, 4.0 * n * (double)T * T * D); LAUNCH_TRY(launch_attention_f32(qkv32, nullptr, h32, n, T, D, h->NH, split ? 16.f : 0.f, st)); }
         if (stop(3)) return CBAS_OK;
         Gemm32VitParams o{};
+        sp(o, 16.f, w.sc_o);
         o.A = h32; o.lda = D; o.W = w.wo32; o.M = M; o.N = D; o.K = D; o.bias = w.o_b; o.lambda = w.ls1; o.out = h->x; o.ldo = D;
         { PROF(CBAS_PROF_OPROJ, 2.0 * M * (double)D * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, o, st)); }
         if (stop(4)) return CBAS_OK;
-        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln2_w, w.ln2_b, h32, M, D, eps, st)); }
+        { PROF(CBAS_PROF_LAYERNORM, 0.0); LAUNCH_TRY(launch_layernorm_f32(h->x, D, w.ln2_w, w.ln2_b, h32, M, D, eps, split, st)); }
         if (stop(5)) return CBAS_OK;
         Gemm32VitParams u{};
+        sp(u, 1.f, w.sc_up);
+        u.out_scale = 4.f;
         u.A = h32; u.lda = D; u.W = w.wup32; u.M = M; u.N = F; u.K = D; u.bias = w.up_b; u.out = u32; u.ldo = F;
         { PROF(CBAS_PROF_UP, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_GELU, u, st)); }
         if (stop(6)) return CBAS_OK;
         Gemm32VitParams d{};
+        sp(d, 4.f, w.sc_down);
         d.A = u32; d.lda = F; d.W = w.wdown32; d.M = M; d.N = D; d.K = F; d.bias = w.down_b; d.lambda = w.ls2; d.out = h->x; d.ldo = D;
         { PROF(CBAS_PROF_DOWN, 2.0 * M * (double)F * D); LAUNCH_TRY(launch_gemm_f32_vit(EPI_RESID, d, st)); }
         if (stop(7)) return CBAS_OK;
@@ -476,7 +496,7 @@ int run_blocks_f32(cbas_enc* h, int n, int height, int width, float* cls_f32, f1
 // Everything after ingest: patch GEMM, L transformer blocks, final CLS norm.
 int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_scale, float* cls_f32,
                f16* cls_f16, hipStream_t st, int stop_layer, int stop_stage) {
-    if (h->cfg.precision == 3) return run_blocks_f32(h, n, height, width, cls_f32, cls_f16, st, stop_layer, stop_stage);
+    if (h->cfg.precision >= 3) return run_blocks_f32(h, n, height, width, cls_f32, cls_f16, st, stop_layer, stop_stage);
     const int ps = h->cfg.patch_size;
     const int nh = height / ps, nw = width / ps, P = nh * nw, T = P + h->NP;
     const int D = h->D, F = h->F;
@@ -610,9 +630,10 @@ int forward_u8_one(cbas_enc* h, const uint8_t* frames_dev, int n, int height, in
                    int stop_layer, int stop_stage) {
     const int ps = h->cfg.patch_size;
     const int T = (height / ps) * (width / ps) + h->NP;
-    if (h->cfg.precision == 3)
+    if (h->cfg.precision >= 3)
         LAUNCH_TRY(launch_im2col_u8_f32(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride,
-                                        reinterpret_cast<float*>(h->A_patch), h->x, h->prefix, h->NP, h->D, T, ps, st));
+                                        reinterpret_cast<float*>(h->A_patch), h->x, h->prefix, h->NP, h->D, T, ps,
+                                        h->cfg.precision == 4, st));
     else
         LAUNCH_TRY(launch_im2col_u8(frames_dev, n, height, width, frame_stride, row_stride, pixel_stride, h->A_patch,
                                     h->x, h->prefix, h->NP, h->D, T, ps, st));
@@ -691,8 +712,9 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         return cbas_fail(CBAS_EINVAL, "intermediate_size=%d must be a multiple of 128", c.intermediate_size);
     if (c.hidden_size > 1024) return cbas_fail(CBAS_EINVAL, "hidden_size > 1024 not supported");
     if (c.patch_size != 16 && c.patch_size != 14) return cbas_fail(CBAS_EINVAL, "patch_size must be 14 or 16");
-    if (c.precision < 0 || c.precision > 3)
-        return cbas_fail(CBAS_EINVAL, "precision=%d: 0 (fp16), 1 (fp16 hi+lo weights), 2 (MX-fp8) or 3 (fp32, the reference's CPU arithmetic)", c.precision);
+    if (c.precision < 0 || c.precision > 4)
+        return cbas_fail(CBAS_EINVAL, "precision=%d: 0 (fp16), 1 (fp16 hi+lo weights), 2 (MX-fp8), 3 (fp32, the reference's CPU arithmetic) "
+                                      "or 4 (fp32 storage, GEMM products as three-term fp16 splits)", c.precision);
     if (c.precision == 2 && (c.hidden_size % 256 || c.intermediate_size % 256))
         return cbas_fail(CBAS_EINVAL, "precision 2 (MX-fp8) needs hidden_size and intermediate_size to be multiples of 256 "
                                       "(K-tiles of 128 consumed in pairs); got %d / %d", c.hidden_size, c.intermediate_size);
@@ -729,11 +751,15 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
 
     // fp16 weight arena: patch (D*256 + D*512) + per layer (3DD + DD + FD + DF)
     const int64_t n16 = D * 256 + D * 512 + (int64_t)h->L * (4 * D * D + 2 * F * D);
-    const bool p3 = c.precision == 3;         // fp32 end to end: no fp16 copies, every workspace 4 bytes per element
+    const bool p3 = c.precision >= 3;         // fp32 end to end (3: fp32 MFMA; 4: three-term fp16 split of the same operands): no fp16 copies, every workspace 4 bytes per element
     if (!p3) CREATE_TRY(hipMalloc(&h->w16, n16 * sizeof(f16)));
     if (c.precision == 1) CREATE_TRY(hipMalloc(&h->w16_lo, n16 * sizeof(f16)));
     float* w32p = nullptr;
-    if (p3) {
+    if (c.precision == 4) {
+        // every weight once more in the split hi | lo format (same byte size as fp32) + a scratch patch weight
+        CREATE_TRY(hipMalloc(&h->w32, (2 * D * 256 + (int64_t)h->L * (4 * D * D + 2 * F * D)) * sizeof(float)));
+        w32p = h->w32;
+    } else if (p3) {
         CREATE_TRY(hipMalloc(&h->w32, (D * 256 + (int64_t)h->L * 3 * D * D) * sizeof(float)));
         w32p = h->w32;
     }
@@ -783,8 +809,36 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
     h->wpatch = w; w += D * 256;
     h->wpatch2 = w; w += D * 512;
     h->wpatch_lo = lo(h->wpatch); h->wpatch2_lo = lo(h->wpatch2);
+    // precision 4: per-tensor power-of-two scales from the HOST copy of the weights (same offsets as the device blob)
+    auto host_max = [&](const float* dev_ptr, int64_t n) {
+        const float* hp = weights_host + (dev_ptr - h->blob);
+        float m = 0.f;
+        for (int64_t i = 0; i < n; ++i) m = std::max(m, fabsf(hp[i]));
+        return m;
+    };
+    auto pow2_scale = [](float maxabs) {                     // 2^s with maxabs * 2^s in [1, 2); 1 for an all-zero tensor
+        if (!(maxabs > 0.f) || !std::isfinite(maxabs)) return 1.0f;
+        int e = 0;
+        (void)frexpf(maxabs, &e);                            // maxabs = f * 2^e, f in [0.5, 1)
+        e = std::min(20, std::max(-20, 1 - e));
+        return ldexpf(1.0f, e);
+    };
     int rc = 0;
-    if (p3) {
+    if (c.precision == 4) {
+        const int pp = c.patch_size * c.patch_size;
+        const float* hw = weights_host + (patch_w - h->blob);
+        float m = 0.f;
+        for (int64_t d = 0; d < D; ++d)
+            for (int k = 0; k < pp; ++k)
+                m = std::max(m, fabsf((hw[d * 3 * pp + k] + hw[d * 3 * pp + pp + k]) + hw[d * 3 * pp + 2 * pp + k]));
+        h->sc_patch = pow2_scale(m);
+    }
+    if (c.precision == 4) {
+        h->wpatch32 = w32p;
+        rc = launch_pack_patch_weight_f32(patch_w, w32p + D * 256, (int)D, c.patch_size, st);      // fp32 sum over channels
+        rc |= launch_pack_split_weight(w32p + D * 256, w32p, D, 256, h->sc_patch, st);
+        w32p += 2 * D * 256;
+    } else if (p3) {
         h->wpatch32 = w32p;
         rc = launch_pack_patch_weight_f32(patch_w, w32p, (int)D, c.patch_size, st);
         w32p += D * 256;
@@ -819,7 +873,24 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         lw.wup = w; w += F * D;
         lw.wdown = w; w += D * F;
         lw.wqkv_lo = lo(lw.wqkv); lw.wo_lo = lo(lw.wo); lw.wup_lo = lo(lw.wup); lw.wdown_lo = lo(lw.wdown);
-        if (p3) {
+        if (c.precision == 4) {
+            lw.sc_qkv = pow2_scale(std::max(host_max(qw, D * D), std::max(host_max(kw, D * D), host_max(vw, D * D))));
+            lw.sc_o = pow2_scale(host_max(ow, D * D));
+            lw.sc_up = pow2_scale(host_max(uw, F * D));
+            lw.sc_down = pow2_scale(host_max(dw, D * F));
+        }
+        if (c.precision == 4) {
+            rc |= launch_pack_split_weight(qw, w32p, D, (int)D, lw.sc_qkv, st);
+            rc |= launch_pack_split_weight(kw, w32p + D * D, D, (int)D, lw.sc_qkv, st);
+            rc |= launch_pack_split_weight(vw, w32p + 2 * D * D, D, (int)D, lw.sc_qkv, st);
+            lw.wqkv32 = w32p; w32p += 3 * D * D;
+            rc |= launch_pack_split_weight(ow, w32p, D, (int)D, lw.sc_o, st);
+            lw.wo32 = w32p; w32p += D * D;
+            rc |= launch_pack_split_weight(uw, w32p, F, (int)D, lw.sc_up, st);
+            lw.wup32 = w32p; w32p += F * D;
+            rc |= launch_pack_split_weight(dw, w32p, D, (int)F, lw.sc_down, st);
+            lw.wdown32 = w32p; w32p += D * F;
+        } else if (p3) {
             // q, k, v sit in the blob with their biases between them: one packed [3D][D] copy; the rest is used in place
             CREATE_TRY(hipMemcpyAsync(w32p, qw, D * D * sizeof(float), hipMemcpyDeviceToDevice, st));
             CREATE_TRY(hipMemcpyAsync(w32p + D * D, kw, D * D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1009,8 +1080,9 @@ extern "C" int cbas_enc_forward_f32(cbas_enc* h, const float* x_dev, int n, int 
     const int T = (height / ps) * (width / ps) + h->NP;
     rc = sync_enter(h, st);
     if (rc) return rc;
-    if (h->cfg.precision == 3)
-        LAUNCH_TRY(launch_im2col_f32_f32(x_dev, n, height, width, reinterpret_cast<float*>(h->A_patch), h->x, h->prefix, h->NP, h->D, T, ps, st));
+    if (h->cfg.precision >= 3)
+        LAUNCH_TRY(launch_im2col_f32_f32(x_dev, n, height, width, reinterpret_cast<float*>(h->A_patch), h->x, h->prefix, h->NP, h->D, T, ps,
+                                         h->cfg.precision == 4, st));
     else
         LAUNCH_TRY(launch_im2col_f32(x_dev, n, height, width, h->A_patch, h->x, h->prefix, h->NP, h->D, T, ps, st));
     rc = run_blocks(h, n, height, width, 512, 1.0f, cls_f32_dev, (f16*)cls_f16_dev, st, -1, -1);
@@ -1036,9 +1108,9 @@ extern "C" int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64
     switch (which) {
         case 0: src = h->x; cap = h->rows_cap * h->D * 4; break;
         // precision 3 keeps these as fp32 (4 bytes per element)
-        case 1: src = h->h16; cap = h->rows_cap * h->D * (h->cfg.precision == 3 ? 4 : 2); break;
-        case 2: src = h->qkv16; cap = h->rows_cap * 3 * h->D * (h->cfg.precision == 3 ? 4 : 2); break;
-        case 3: src = h->u16; cap = h->rows_cap * h->F * (h->cfg.precision == 3 ? 4 : 2); break;
+        case 1: src = h->h16; cap = h->rows_cap * h->D * (h->cfg.precision >= 3 ? 4 : 2); break;
+        case 2: src = h->qkv16; cap = h->rows_cap * 3 * h->D * (h->cfg.precision >= 3 ? 4 : 2); break;
+        case 3: src = h->u16; cap = h->rows_cap * h->F * (h->cfg.precision >= 3 ? 4 : 2); break;
         default: return cbas_fail(CBAS_EINVAL, "unknown buffer %d", which);
     }
     if (n_bytes < 0 || n_bytes > cap) return cbas_fail(CBAS_EINVAL, "read of %lld bytes exceeds buffer (%lld)", (long long)n_bytes, (long long)cap);

@@ -160,24 +160,34 @@ struct Gemm32VitParams {
     const float* rope_sin;
     int D;                         // hidden size (q | k | v sections of width D)
     int sec0;                      // section of output column 0
+    // precision 4: the same fp32 operands, products on the fp16 matrix pipe as a three-term split (vit_f32.hip).
+    // a_scale / w_scale: powers of two the operands are multiplied by before the split (keeps the low halves out of
+    // fp16's subnormal range); the accumulators are multiplied by 1 / (a_scale * w_scale) - all exact.
+    int split;                     // A and W are in the split format (vit_f32.hip); EPI_GELU then writes its output split too
+    float a_scale, w_scale;        // the scales A and W were split with
+    float out_scale;               // EPI_GELU with split: scale of the split output (the down projection's a_scale)
 };
 int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream);
 // uint8 pixels -> A[n*P][256] fp32 = float(double(pixel) / 255.0), the reference's cbas.py:431 value bit for bit
 // (+ prefix rows of x, as launch_im2col_u8)
+// split != 0 (precision 4): A in the split hi | lo format of vit_f32.hip
 int launch_im2col_u8_f32(const uint8_t* frames, int n, int height, int width, int64_t frame_stride, int64_t row_stride,
                          int64_t pixel_stride, float* A, float* x, const float* prefix_tokens, int n_prefix, int D, int T,
-                         int ps, hipStream_t stream);
+                         int ps, int split, hipStream_t stream);
 // float32 (n,H,W) -> A[n*P][256] fp32, values as they are
 int launch_im2col_f32_f32(const float* frames, int n, int height, int width, float* A, float* x,
-                          const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream);
+                          const float* prefix_tokens, int n_prefix, int D, int T, int ps, int split, hipStream_t stream);
+// precision 4: fp32 weight [N][K] -> split format at the same byte size, values multiplied by `scale` first
+int launch_pack_split_weight(const float* w, float* out, int64_t N, int K, float scale, hipStream_t stream);
 // patch weight (D,3,ps,ps) fp32 -> (D,256) fp32 in the 16x16 slot layout, summed over the 3 identical input channels in
 // double and rounded once
 int launch_pack_patch_weight_f32(const float* w, float* out, int D, int ps, hipStream_t stream);
 int launch_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int M, int D,
-                         float eps, hipStream_t stream);
+                         float eps, int split, hipStream_t stream);
 // qkv [n*T][3D] fp32 (q pre-scaled by 1/8, RoPE applied) -> out [n*T][D] fp32; q_cls as launch_attention
+// split_scale > 0 (precision 4): the context is written in the split format, multiplied by split_scale
 int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n, int T, int D, int n_heads,
-                         hipStream_t stream);
+                         float split_scale, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // classifier head (all fp32)

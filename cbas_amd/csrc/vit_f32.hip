@@ -25,6 +25,39 @@ namespace {
 
 using namespace f32tile;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// precision 4: the same fp32 schedule with every GEMM's products on the fp16 matrix pipe.  An fp32 value x (times a power
+// of two) is kept as hi + lo, hi = fp16(x), lo = fp16(x - hi): 22 significant bits;
+//      a w  ~  a_hi w_hi + a_hi w_lo + a_lo w_hi        on v_mfma_f32_16x16x32_f16
+// (fp16 products are exact in fp32; the dropped a_lo w_lo term and the two representation residues are ~2^-22 of the
+// product each; the MFMA sums a 32-product block before it rounds into the fp32 accumulator, which makes the result
+// CLOSER to the reference's blocked CPU GEMM than the k-ordered fmaf chain of precision 3: measured).
+//
+// Split operands live in memory in the GEMM's LDS image order, at the byte size of the fp32 array they replace: the 32
+// k-values of a K-tile of a row are 128 bytes = [hi: 32 x fp16 | lo: 32 x fp16], and inside each half the value of
+// k = 16 h + 4 g + e (h = 0, 1; g, e = 0..3) sits at position 8 g + 4 h + e - so the 16-byte chunk g of the hi half (chunk
+// 4 + g for lo) is exactly the 8 k-values lane group g feeds one MFMA, and the staging / swizzle / fragment reads are the
+// fp32 kernel's own.  Producers (LayerNorm, attention, the GELU epilogue, ingest, the weight packer) write this format,
+// each value split ONCE; the GEMM loop is fragment reads + 48 MFMAs per K-tile per wave, no conversions.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+// four consecutive columns c .. c+3 (c % 4 == 0) of a row that starts at `row` (float-sized slots): hi and lo halves
+__device__ __forceinline__ void store_split4(float* row, int c, f32x4 v, float scale) {
+    const int kk = c & 31;
+    char* tile = reinterpret_cast<char*>(row + (c - kk));                       // the K-tile's 128 bytes
+    const int pos = (((kk & 15) >> 2) << 3) + ((kk >> 4) << 2);                 // 8 g + 4 h
+    f16x4v hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e] * scale;
+        const f16 h = (f16)x;
+        hi[e] = h;
+        lo[e] = (f16)(x - (float)h);
+    }
+    *reinterpret_cast<f16x4v*>(tile + pos * 2) = hi;
+    *reinterpret_cast<f16x4v*>(tile + 64 + pos * 2) = lo;
+}
+
 // a*c + b*s with every product and the sum rounded on its own, as the reference's `(q * cos) + (rotate_half(q) * sin)`
 __device__ __forceinline__ f32x4 rope_rot32(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
 #pragma clang fp contract(off)
@@ -89,12 +122,14 @@ __device__ __forceinline__ void vit32_epilogue_row(const Gemm32VitParams& p, int
         for (int j = 0; j < 4; ++j) {
             const int n = ncol + j * 16;
             const f32x4 w = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + n);
-            *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = f32x4{gelu_erf(w[0]), gelu_erf(w[1]), gelu_erf(w[2]), gelu_erf(w[3])};
+            const f32x4 gv = f32x4{gelu_erf(w[0]), gelu_erf(w[1]), gelu_erf(w[2]), gelu_erf(w[3])};
+            if (p.split) store_split4(p.out + (int64_t)m * p.ldo, n, gv, p.out_scale);      // the down projection's A operand
+            else *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = gv;
         }
     }
 }
 
-template <int EPI>
+template <int EPI, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_vit_kernel(Gemm32VitParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_BYTES = 2 * TILE_BYTES;
@@ -130,25 +165,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_vit_kernel(Gemm32VitParams p)
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* At = smem + cur * BUF_BYTES;
         const char* Wt = At + TILE_BYTES;
+        if constexpr (SPLIT) {
+            // one K-tile = 32 k = ONE fp16 MFMA k-step; both operands arrive split (see above): chunk g = hi, 4 + g = lo
+            f16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f32x4 a[4], b[4];
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = __builtin_bit_cast(f16x8, read_frag32(At, wr * 64 + i * 16 + frow, fchunk));
+                al[i] = __builtin_bit_cast(f16x8, read_frag32(At, wr * 64 + i * 16 + frow, 4 + fchunk));
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = read_frag32(At, wr * 64 + i * 16 + frow, kk * 4 + fchunk);
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = __builtin_bit_cast(f16x8, read_frag32(Wt, wc * 64 + j * 16 + frow, fchunk));
+                bl[j] = __builtin_bit_cast(f16x8, read_frag32(Wt, wc * 64 + j * 16 + frow, 4 + fchunk));
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = read_frag32(Wt, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                }
+        } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x4 a[4], b[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) a[i] = read_frag32(At, wr * 64 + i * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = read_frag32(Wt, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    if constexpr (SPLIT) {
+        const float unscale = 1.0f / (p.a_scale * p.w_scale);     // powers of two: exact
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= unscale;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = row0 + wr * 64 + i * 16 + (lane & 15);
@@ -156,20 +221,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_vit_kernel(Gemm32VitParams p)
     }
 }
 
-template <int EPI>
-int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
+template <int EPI, bool SPLIT>
+int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
     constexpr int lds = 4 * TILE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_vit_kernel<EPI>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_vit_kernel<EPI, SPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return -2;
         attr_set = true;
     }
     const int64_t grid = ((int64_t)(p.M + BM - 1) / BM) * (p.N / BN);
     if (grid <= 0 || grid > 0x7fffffff) return -1;
-    hipLaunchKernelGGL((gemm_f32_vit_kernel<EPI>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f32_vit_kernel<EPI, SPLIT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int EPI>
+int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
+    // (r4: a 256 x 128 tile with 8 waves and a 3-stage LDS ring - two K-tiles in flight under a counted vmcnt - was built for
+    //  the split form and measured: 9.90 ms per 64-frame ViT-B step against 9.35 ms with this two-buffer kernel at two
+    //  workgroups per CU; both run the split GEMMs at the fused fp16 kernel's rate, ~0.9 PF/s of executed MFMA work.  Removed.)
+    return p.split ? launch_vit32s<EPI, true>(p, stream) : launch_vit32s<EPI, false>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +252,7 @@ int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
 // with i >= ps or j >= ps stay zero: rows i >= ps are never written, the buffer is zeroed at allocation).
 template <typename SRC>
 __global__ void im2col_f32out_kernel(const SRC* __restrict__ frames, int n, int64_t frame_stride, int64_t row_stride,
-                                     int64_t pixel_stride, float* __restrict__ A, int nh, int nw, int ps) {
+                                     int64_t pixel_stride, float* __restrict__ A, int nh, int nw, int ps, int split) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)n * nh * ps * nw;
     if (gid >= total) return;
@@ -203,7 +276,8 @@ __global__ void im2col_f32out_kernel(const SRC* __restrict__ frames, int n, int6
             }
             v[e] = f;
         }
-        reinterpret_cast<f32x4*>(dst)[q] = v;
+        if (split) store_split4(dst - i * 16, i * 16 + q * 4, v, 1.0f);
+        else reinterpret_cast<f32x4*>(dst)[q] = v;
     }
 }
 
@@ -229,11 +303,21 @@ __global__ void pack_patch_weight_f32_kernel(const float* __restrict__ w, float*
     out[idx] = v;
 }
 
+// precision 4: fp32 weight [N][K] -> split format (same byte size), values scaled by `scale` (a power of two); K % 32 == 0
+__global__ void pack_split_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int64_t N, int K, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread = 4 consecutive k of one row
+    const int per_row = K >> 2;
+    if (i >= N * per_row) return;
+    const int64_t row = i / per_row;
+    const int c = (int)(i - row * per_row) * 4;
+    store_split4(out + row * K, c, *reinterpret_cast<const f32x4*>(w + row * K + c), scale);
+}
+
 // one wave per row, two-pass statistics in registers
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ out, int M, int D,
-                                                            float eps) {
+                                                            float eps, int split) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -264,7 +348,9 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
         if (idx < nvec) {
             const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[idx];
             const f32x4 bb = reinterpret_cast<const f32x4*>(beta)[idx];
-            reinterpret_cast<f32x4*>(out + (size_t)row * D)[idx] = (v[k] - mean) * rstd * g + bb;
+            const f32x4 y = (v[k] - mean) * rstd * g + bb;
+            if (split) store_split4(out + (size_t)row * D, idx * 4, y, 1.0f);
+            else reinterpret_cast<f32x4*>(out + (size_t)row * D)[idx] = y;
         }
     }
 }
@@ -286,7 +372,8 @@ constexpr int AKB = 64;                     // keys per block
 constexpr int AIMG = AKB * 256;             // bytes of one K or V block image
 
 __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
-                                                               float* __restrict__ out, int T, int D, int n_heads, int qblocks) {
+                                                               float* __restrict__ out, int T, int D, int n_heads, int qblocks,
+                                                               float split_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
@@ -393,9 +480,13 @@ __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __re
     lrun = xor16_add(lrun);
     lrun = xor32_add(lrun);
     if (q < nq) {
-        float* orow = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D + hd * 64 + 4 * g;
+        float* row = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = o[dt] / lrun;
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 v = o[dt] / lrun;
+            if (split_scale > 0.f) store_split4(row, hd * 64 + 16 * dt + 4 * g, v, split_scale);   // precision 4: o_proj's A operand
+            else *reinterpret_cast<f32x4*>(row + hd * 64 + 16 * dt + 4 * g) = v;
+        }
     }
 }
 
@@ -406,6 +497,7 @@ __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __re
 int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.N % BN || p.K % BKF || p.lda % 4 || p.ldo % 4) return -1;
     if (epi == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;
+    if (p.split && !(p.a_scale > 0.f && p.w_scale > 0.f)) return -1;
     switch (epi) {
         case EPI_PATCH: return launch_vit32<EPI_PATCH>(p, stream);
         case EPI_QKV:   return launch_vit32<EPI_QKV>(p, stream);
@@ -417,11 +509,11 @@ int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t 
 
 int launch_im2col_u8_f32(const uint8_t* frames, int n, int height, int width, int64_t frame_stride, int64_t row_stride,
                          int64_t pixel_stride, float* A, float* x, const float* prefix_tokens, int n_prefix, int D, int T,
-                         int ps, hipStream_t stream) {
+                         int ps, int split, hipStream_t stream) {
     const int nh = height / ps, nw = width / ps;
     const int64_t total = (int64_t)n * nh * ps * nw;
     hipLaunchKernelGGL(im2col_f32out_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
-                       frame_stride, row_stride, pixel_stride, A, nh, nw, ps);
+                       frame_stride, row_stride, pixel_stride, A, nh, nw, ps, split);
     const int64_t tp = (int64_t)n * n_prefix * (D / 4);
     hipLaunchKernelGGL(write_prefix32_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens, n,
                        n_prefix, D, T);
@@ -429,14 +521,21 @@ int launch_im2col_u8_f32(const uint8_t* frames, int n, int height, int width, in
 }
 
 int launch_im2col_f32_f32(const float* frames, int n, int height, int width, float* A, float* x,
-                          const float* prefix_tokens, int n_prefix, int D, int T, int ps, hipStream_t stream) {
+                          const float* prefix_tokens, int n_prefix, int D, int T, int ps, int split, hipStream_t stream) {
     const int nh = height / ps, nw = width / ps;
     const int64_t total = (int64_t)n * nh * ps * nw;
     hipLaunchKernelGGL(im2col_f32out_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, frames, n,
-                       (int64_t)height * width, (int64_t)width, (int64_t)1, A, nh, nw, ps);
+                       (int64_t)height * width, (int64_t)width, (int64_t)1, A, nh, nw, ps, split);
     const int64_t tp = (int64_t)n * n_prefix * (D / 4);
     hipLaunchKernelGGL(write_prefix32_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, stream, x, prefix_tokens, n,
                        n_prefix, D, T);
+    return CHECK_LAUNCH();
+}
+
+int launch_pack_split_weight(const float* w, float* out, int64_t N, int K, float scale, hipStream_t stream) {
+    if (K % 32 || N <= 0) return -1;
+    const int64_t n4 = N * (K / 4);
+    hipLaunchKernelGGL(pack_split_weight_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, w, out, N, K, scale);
     return CHECK_LAUNCH();
 }
 
@@ -446,21 +545,22 @@ int launch_pack_patch_weight_f32(const float* w, float* out, int D, int ps, hipS
 }
 
 int launch_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int M, int D,
-                         float eps, hipStream_t stream) {
+                         float eps, int split, hipStream_t stream) {
+    if (split && D % 32) return -1;
     const int nv = (D / 4 + 63) / 64;
     const dim3 grid((M + 3) / 4), block(256);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
-        case 2: hipLaunchKernelGGL(layernorm_f32_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
-        case 3: hipLaunchKernelGGL(layernorm_f32_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
-        case 4: hipLaunchKernelGGL(layernorm_f32_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps); break;
+        case 1: hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps, split); break;
+        case 2: hipLaunchKernelGGL(layernorm_f32_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps, split); break;
+        case 3: hipLaunchKernelGGL(layernorm_f32_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps, split); break;
+        case 4: hipLaunchKernelGGL(layernorm_f32_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, out, M, D, eps, split); break;
         default: return -1;
     }
     return CHECK_LAUNCH();
 }
 
 int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n, int T, int D, int n_heads,
-                         hipStream_t stream) {
+                         float split_scale, hipStream_t stream) {
     if (n <= 0 || T <= 0 || D != n_heads * 64) return -1;
     static bool attr_set = false;
     constexpr int lds = 4 * AIMG;                           // two buffers x (K + V) = 64 KiB: two workgroups per CU
@@ -482,6 +582,6 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
     const int qblocks = (ntiles + nw - 1) / nw;
     const int64_t grid = (int64_t)n * n_heads * qblocks;
     if (grid > 0x7fffffff) return -1;
-    hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks, split_scale);
     return CHECK_LAUNCH();
 }

@@ -120,7 +120,8 @@ class DinoEncoder:
     @property
     def precision(self) -> int:
         """0 fp16 (default), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode, 3 fp32 end to end - the reference's CPU
-        arithmetic, for label-exact runs (include/cbas_mi355x.h)."""
+        arithmetic, for label-exact runs, 4 the same with the GEMM products as three-term fp16 splits (as exact, twice as
+        fast) (include/cbas_mi355x.h)."""
         return int(self._cfg_c.precision)
 
     # -- nn.Module-like surface used by the reference ------------------------------------------
@@ -293,7 +294,9 @@ class DinoEncoder:
                                                        stop_layer, stop_stage), "cbas_enc_debug_forward_u8")
         T = self.config.num_tokens(H, W)
         D, F = self.config.hidden_size, self.config.intermediate_size
-        act = np.float32 if self.precision == 3 else np.float16        # precision 3 keeps every activation buffer fp32
+        if self.precision == 4 and which in (1, 3):
+            raise RuntimeError("precision 4 keeps the LayerNorm / GELU buffers in the GEMM's split hi|lo tile order; tap precision 3")
+        act = np.float32 if self.precision >= 3 else np.float16        # precision 3 / 4 keep every activation buffer fp32
         shape, dt = {0: ((n * T, D), np.float32), 1: ((n * T, D), act), 2: ((n * T, 3 * D), act),
                      3: ((n * T, F), act)}[which]
         out = np.empty(shape, dt)

@@ -86,7 +86,14 @@ typedef struct cbas_enc_config {
                                         v_mfma_f32_16x16x4_f32 (exact fp32 products and sums), the element-wise steps
                                         rounded where the reference's separate torch ops round.  CLS rows agree with
                                         the reference to a few 1e-6, so the fp16 rows written to _cls.h5 and the argmax
-                                        labels are the reference's own.  ~1/7 of the default mode's frame rate. */
+                                        labels are the reference's own.  ~1/7 of the default mode's frame rate.
+                                     4: precision 3's buffers, element-wise arithmetic and attention, with every GEMM product
+                                        formed on the fp16 matrix pipe from split operands: x = hi + lo (two fp16 halves, 22
+                                        significant bits, stored in the GEMM's own tile order by the producing kernels and by
+                                        the weight packer), a w ~ a_hi w_hi + a_hi w_lo + a_lo w_hi on
+                                        v_mfma_f32_16x16x32_f16 with fp32 accumulation.  CLS rows are as close to the
+                                        reference as precision 3's (measured: slightly closer - the MFMA sums each block of 32
+                                        products before rounding into the accumulator); twice its frame rate. */
     int32_t use_rope;             /* 1: DINOv3 (RoPE on patch rows, no additive position embedding)     */
     int32_t pos_embed_grid;       /* G > 0: DINOv2-with-registers, learned (1+G*G, D) position embedding,
                                      bicubic-antialias interpolated to each frame's patch grid; else 0 */

@@ -1,6 +1,8 @@
-"""precision 3: the encoder in the reference's own CPU arithmetic (fp32 operands, products and sums on
-v_mfma_f32_16x16x4_f32; cbas_amd/csrc/vit_f32.hip).  This is the mode that meets BASELINE.json's "identical argmax
-labels" literally: the gates below have NO near-tie relaxation - every label of the reference's own end-to-end
+"""precision 3 and 4: the encoder in the reference's own CPU arithmetic (cbas_amd/csrc/vit_f32.hip) - fp32 storage,
+attention, LayerNorm and element-wise steps in both; the GEMMs on v_mfma_f32_16x16x4_f32 (3: exact fp32 products and
+sums) or on v_mfma_f32_16x16x32_f16 from operands split into two fp16 halves (4: three-term products, 22 bits, fp32
+accumulation - as close to the reference, twice as fast).  These are the modes that meet BASELINE.json's "identical
+argmax labels" literally: the gates below have NO near-tie relaxation - every label of the reference's own end-to-end
 fixtures must be reproduced, CLS rows within a few 1e-6 of the reference's fp32 CPU output."""
 import os
 
@@ -24,10 +26,13 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-def make_enc(cfg, hw, max_batch):
+PRECISIONS = (3, 4)
+
+
+def make_enc(cfg, hw, max_batch, precision=3):
     from cbas_amd.encoder import DinoEncoder
     return DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=max_batch, max_frame=(hw, hw),
-                                    precision=3)
+                                    precision=precision)
 
 
 def make_head(dim):
@@ -74,10 +79,11 @@ def test_fp32_tiny_stagewise_against_oracle():
         enc.close()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name,cfgname,hw", [("vits16_224", "vits16", 224), ("vitb16_224", "vitb16", 224),
                                              ("vitb16_224_noise", "vitb16", 224), ("vitb16_256", "vitb16", 256),
                                              ("vitl16_224", "vitl16", 224), ("vitl16_518", "vitl16", 518)])
-def test_fp32_cls_goldens(golden_dir, name, cfgname, hw):
+def test_fp32_cls_goldens(golden_dir, name, cfgname, hw, precision):
     """CLS rows of the reference's own fp32 forward (HF DINOv3ViTModel on CPU), every committed model / size, incl. the
     DINOv2-free T = 1029 case that streams 17 key blocks through the attention kernel."""
     g = load(golden_dir, name)
@@ -85,12 +91,12 @@ def test_fp32_cls_goldens(golden_dir, name, cfgname, hw):
     n = int(g["n"])
     mk = synth.noise_frames if str(g["kind"]) == "noise" else synth.cage_frames
     fr = mk(int(g["frame_seed"]), n, hw, hw)
-    enc = make_enc(cfg, hw, 8)
+    enc = make_enc(cfg, hw, 8, precision)
     try:
         c16, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
         torch.cuda.synchronize()
         r = rel_rows(c32.cpu().numpy(), g["cls"])
-        print(f"[fp32 {name}] CLS rel err max {r.max():.3e}")
+        print(f"[precision {precision} {name}] CLS rel err max {r.max():.3e}")
         assert r.max() < CLS_TOL_F32, r.max()
         assert np.array_equal(c16.cpu().numpy(), c32.cpu().numpy().astype(np.float16))
         # pruned last layer == full last layer, bit for bit (rows are independent, same k order)
@@ -102,14 +108,15 @@ def test_fp32_cls_goldens(golden_dir, name, cfgname, hw):
         enc.close()
 
 
-def test_fp32_float_input_is_the_same_arithmetic(golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_float_input_is_the_same_arithmetic(golden_dir, precision):
     """DinoEncoder.__call__ on the reference's float tensor (green / 255.0, cbas.py:431-435) == the uint8 path bit for bit:
     the ingest kernel forms float(double(pixel) / 255.0), the value numpy hands the reference."""
     from oracle import vit_oracle as V
     g = load(golden_dir, "vits16_224")
     cfg = C.VIT_S16
     fr = synth.cage_frames(int(g["frame_seed"]), int(g["n"]), 224, 224)
-    enc = make_enc(cfg, 224, 8)
+    enc = make_enc(cfg, 224, 8, precision)
     try:
         _, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
         x = torch.from_numpy((fr[:, :, :, 1] / 255.0).astype(np.float32)).cuda().unsqueeze(1)
@@ -121,10 +128,11 @@ def test_fp32_float_input_is_the_same_arithmetic(golden_dir):
         enc.close()
 
 
-def test_fp32_batch_invariance_at_the_bench_batch():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_batch_invariance_at_the_bench_batch(precision):
     """64 x 224^2 (M = 12 864 rows): a frame's row does not depend on its batch size or position (bit-exact)."""
     cfg = C.VIT_B16
-    enc = make_enc(cfg, 224, 64)
+    enc = make_enc(cfg, 224, 64, precision)
     try:
         fr = synth.noise_frames(5, 8, 224, 224)
         big = np.concatenate([fr] * 8)
@@ -140,12 +148,12 @@ def test_fp32_batch_invariance_at_the_bench_batch():
         enc.close()
 
 
-def _e2e(golden_dir, name, cfg, dim, batch):
+def _e2e(golden_dir, name, cfg, dim, batch, precision=3):
     from cbas_amd.stream import ClipStream
     g = load(golden_dir, name)
     n = int(g["n"])
     fr = synth.cage_frames(int(g["frame_seed"]), n, 224, 224)
-    enc = make_enc(cfg, 224, batch)
+    enc = make_enc(cfg, 224, batch, precision)
     head = make_head(dim)
     try:
         st = ClipStream(enc, head, capacity=n)
@@ -185,37 +193,41 @@ def _strict_gate(golden_dir, tag, name, g, cls16, probs, ref_cls32, sel):
     assert ulp.mean() < 2e-2
 
 
-def test_fp32_e2e_config1_labels_identical(golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_e2e_config1_labels_identical(golden_dir, precision):
     """BASELINE config 1 (ViT-S/16, 64 frames, C = 9) against the reference's own encoder + infer_file outputs:
     EVERY argmax label identical - no near-tie band."""
-    g, cls16, probs = _e2e(golden_dir, "e2e_vits16", C.VIT_S16, 384, 8)
-    _strict_gate(golden_dir, "fp32 e2e_vits16", "e2e_vits16", g, cls16, probs, g["cls"], slice(None))
+    g, cls16, probs = _e2e(golden_dir, "e2e_vits16", C.VIT_S16, 384, 8, precision)
+    _strict_gate(golden_dir, f"precision {precision} e2e_vits16", "e2e_vits16", g, cls16, probs, g["cls"], slice(None))
 
 
-def test_fp32_e2e_config2_model_labels_identical(golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_e2e_config2_model_labels_identical(golden_dir, precision):
     """The headline model (ViT-B/16 through the reference's own DinoEncoder wrapper, 256 frames): every label identical -
     frame 69 (reference top-2 margin 4.1e-5) either way: the reference itself labels it both ways, depending on how many
     frames it hands its encoder per call (tests/golden/e2e_vitb16_variants.npz)."""
-    g, cls16, probs = _e2e(golden_dir, "e2e_vitb16", C.VIT_B16, 768, 64)
-    _strict_gate(golden_dir, "fp32 e2e_vitb16", "e2e_vitb16", g, cls16, probs, g["cls"], slice(None))
+    g, cls16, probs = _e2e(golden_dir, "e2e_vitb16", C.VIT_B16, 768, 64, precision)
+    _strict_gate(golden_dir, f"precision {precision} e2e_vitb16", "e2e_vitb16", g, cls16, probs, g["cls"], slice(None))
 
 
-def test_fp32_e2e_long_clip_labels_identical(golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_e2e_long_clip_labels_identical(golden_dir, precision):
     """2 048 frames of the headline model, dozens of behaviour transitions: every label identical."""
     if not os.path.exists(os.path.join(golden_dir, "e2e_vitb16_long.npz")):
         pytest.skip("long fixture not generated")
-    g, cls16, probs = _e2e(golden_dir, "e2e_vitb16_long", C.VIT_B16, 768, 64)
-    _strict_gate(golden_dir, "fp32 e2e_vitb16_long", "e2e_vitb16_long", g, cls16, probs, g["cls_every8"], slice(0, None, 8))
+    g, cls16, probs = _e2e(golden_dir, "e2e_vitb16_long", C.VIT_B16, 768, 64, precision)
+    _strict_gate(golden_dir, f"precision {precision} e2e_vitb16_long", "e2e_vitb16_long", g, cls16, probs, g["cls_every8"], slice(0, None, 8))
 
 
-def test_fp32_dinov2_with_registers(golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_dinov2_with_registers(golden_dir, precision):
     """CBAS's default encoder family in precision 3 (patch 14, interpolated position embedding, key bias, no RoPE, LN eps
     1e-6): the tiny model's embeddings (incl. the bicubic-antialias interpolation) and CLS at three frame sizes, ViT-B/14 at
     224 and 256 against HF Dinov2WithRegistersModel / the reference's own wrapper - to fp32 rounding."""
     from cbas_amd.encoder import DinoEncoder
     g = load(golden_dir, "dinov2reg_tiny")
     cfg = C.DINOV2_REG_TINY
-    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(84, 84), precision=3)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(84, 84), precision=precision)
     try:
         for hw in (70, 56, 84, 70):
             fr = synth.cage_frames(20 + hw, 3, hw, hw)
@@ -230,20 +242,21 @@ def test_fp32_dinov2_with_registers(golden_dir):
         enc.close()
     g = load(golden_dir, "dinov2reg_b14")
     cfg = C.DINOV2_REG_B14
-    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(256, 256), precision=3)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=4, max_frame=(256, 256), precision=precision)
     try:
         for hw, seed, n in ((224, 31, 4), (256, 32, 2)):
             fr = synth.cage_frames(seed, n, hw, hw)
             _, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
             torch.cuda.synchronize()
             r = rel_rows(c32.cpu().numpy(), g[f"cls{hw}"])
-            print(f"[fp32 dinov2reg_b14 {hw}] CLS rel err max {r.max():.3e}")
+            print(f"[precision {precision} dinov2reg_b14 {hw}] CLS rel err max {r.max():.3e}")
             assert r.max() < CLS_TOL_F32, (hw, r.max())
     finally:
         enc.close()
 
 
-def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, tmp_path):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, tmp_path, precision):
     """encode_file / infer_file / encode_infer_file with a precision-3 encoder, against the `_cls.h5` rows the REFERENCE's
     own encode_file wrote for the same 600-frame 'video' (tests/golden/encode_file_b1layer.npz): the fp16 rows are the
     reference's except where a value sits on a rounding boundary (well under 1 % of the elements, one ulp each) - the
@@ -252,7 +265,7 @@ def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, 
     from cbas_amd.encoder import DinoEncoder
     g = load(golden_dir, "encode_file_b1layer")
     cfg = C.ViTConfig(hidden_size=768, intermediate_size=1536, num_hidden_layers=1, num_attention_heads=12, image_size=32)
-    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(32, 32), precision=3)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(32, 32), precision=precision)
     head = make_head(768)
     try:
         frames = synth.cage_frames(5, 600, 32, 32)
