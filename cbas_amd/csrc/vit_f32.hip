@@ -1,4 +1,6 @@
-// Precision 3: the encoder in the reference's own CPU arithmetic - fp32 operands, fp32 products, fp32 sums - on gfx950.
+// Precision 3 (and 4): the encoder in the reference's own CPU arithmetic - fp32 operands, fp32 products, fp32 sums - on
+// gfx950; precision 4 keeps this file's buffers, attention, LayerNorm and epilogues and forms the GEMM products on the fp16
+// matrix pipe from split operands (see "precision 4" below).
 //
 // The reference's parity target is its CPU path: autocast is disabled there (backend/cbas.py:433-434), so every
 // nn.Linear of [tf] modeling_dinov3_vit.py runs as an fp32 GEMM, attention as fp32 SDPA, LayerNorm / GELU / RoPE in
@@ -423,10 +425,15 @@ __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __re
         if (active) {
             const char* Ks = smem + cur * 2 * AIMG;
             const char* Vs = Ks + AIMG;
+            // key tiles of this block that hold at least one real key (wave-uniform; 4 except in the last block: T = 201
+            // leaves 9 keys = one tile there, so three quarters of that block's MFMAs are skipped)
+            const int left = T - kb * AKB;
+            const int nkt = left >= AKB ? 4 : (left + 15) >> 4;
             f32x4 s[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (kt >= nkt) { s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + li) * 256 + (((4 * c + g) ^ li) << 4));
@@ -462,7 +469,8 @@ __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __re
             for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
             const int vsw = (g & 1) << 2;                   // ((row >> 2) & 1) << 2 for row = 16 kt + 4g + r
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) continue;                    // probabilities of a padded tile are exactly 0
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const char* vrow = Vs + (kt * 16 + 4 * g + r) * 256 + ((li & 3) << 2);
@@ -472,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __re
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][r], o[dt], 0, 0, 0);
                     }
                 }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
