@@ -60,6 +60,24 @@ __device__ __forceinline__ void store_split4(float* row, int c, f32x4 v, float s
     *reinterpret_cast<f16x4v*>(tile + 64 + pos * 2) = lo;
 }
 
+// Attention operands of precision 4: the 64 values of one head of q, k or v (256 bytes as fp32) become
+// [hi: 64 x fp16 | lo: 64 x fp16] in natural d order - 128-byte rows, the fp16 attention kernels' K / V row geometry.
+// Scales (powers of two, undone exactly in the kernel): q x 16 on top of its 1/8, k x 4, v x 4; probabilities x 1024.
+constexpr float ATT_QS = 16.f, ATT_KS = 4.f, ATT_VS = 4.f, ATT_PS = 1024.f;
+__device__ __forceinline__ void store_head_split4(float* head, int d, f32x4 v, float scale) {
+    f16x4v hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e] * scale;
+        const f16 h = (f16)x;
+        hi[e] = h;
+        lo[e] = (f16)(x - (float)h);
+    }
+    char* b = reinterpret_cast<char*>(head);
+    *reinterpret_cast<f16x4v*>(b + d * 2) = hi;
+    *reinterpret_cast<f16x4v*>(b + 128 + d * 2) = lo;
+}
+
 // a*c + b*s with every product and the sum rounded on its own, as the reference's `(q * cos) + (rotate_half(q) * sin)`
 __device__ __forceinline__ f32x4 rope_rot32(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
 #pragma clang fp contract(off)
@@ -105,6 +123,13 @@ __device__ __forceinline__ void vit32_epilogue_row(const Gemm32VitParams& p, int
             for (int j = 0; j < 4; ++j) v[j] = o[j];
         }
         const float qs = (sec == 0) ? 0.125f : 1.0f;   // head_dim^-0.5, an exact power of two: commutes with every rounding
+        if (p.split) {                                  // precision 4: the attention kernel's split operands
+            const float sc = sec == 0 ? 0.125f * ATT_QS : (sec == 1 ? ATT_KS : ATT_VS);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                store_head_split4(p.out + (int64_t)m * p.ldo + head_col0, j * 16 + (lane >> 4) * 4, v[j], sc);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + ncol + j * 16) = v[j] * qs;
@@ -499,6 +524,161 @@ __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Attention, precision 4: the structure of attention_f32_kernel (64-key blocks through a 2-deep LDS ring, S^T = K Q^T so
+// that a lane holds its query's keys, online softmax in fp32 with the accurate expf) with both products on the fp16 pipe
+// from split operands: S^T = K_hi Q_hi + K_hi Q_lo + K_lo Q_hi (6 MFMAs per 16-key tile), O^T = V_hi P_hi + V_hi P_lo +
+// V_lo P_hi (12 per 32-key group), 48 x 16 cycles per block and wave against 128 x 32.  q, k, v arrive split from the
+// q|k|v epilogue (store_head_split4); the probabilities are split in registers (x 1024 first: a softmax tail would
+// otherwise sit in fp16's subnormals).  K / V images and fragment reads are those of the fp16 kernels (vit_kernels.hip:
+// 128-byte rows, k_off / v_off swizzles applied on the DMA source, V through ds_read_b64_tr_b16), once for the hi and
+// once for the lo halves: 4 images x 8 KiB per buffer.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sk_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int sv_off(int row, int col) {   // col in halves
+    return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
+}
+constexpr int SIMG = AKB * 128;             // bytes of one hi or lo image of a 64-key block
+
+__global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
+                                                                 float* __restrict__ out, int T, int D, int n_heads, int qblocks,
+                                                                 float out_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [buf][K_hi | K_lo | V_hi | V_lo][64 keys][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    const int pair = blockIdx.x / qblocks, qb = blockIdx.x - pair * qblocks;
+    const int b = pair / n_heads, hd = pair - b * n_heads;
+    const size_t ldb = (size_t)3 * D * 4;                              // bytes per token row
+    const char* qbase = reinterpret_cast<const char*>(qkv) + (size_t)b * T * ldb + (size_t)hd * 256;
+    const char* kbase = qbase + (size_t)D * 4;
+    const char* vbase = qbase + (size_t)D * 8;
+    const int g = lane >> 4, li = lane & 15;
+    const int nq = q_cls ? 1 : T;
+    const int qt = qb * nwaves + wave;
+    const bool active = qt * 16 < nq;                                  // wave-uniform
+    const int q = qt * 16 + li;
+    const int qrow = q < nq ? q : nq - 1;
+    const char* qsrc = q_cls ? reinterpret_cast<const char*>(q_cls) + (size_t)b * D * 4 + (size_t)hd * 256 : qbase + (size_t)qrow * ldb;
+    f16x8 qh[2], ql[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {                                   // k-half h2: d in [32 h2, 32 h2 + 32): chunk 4 h2 + g
+        qh[h2] = *reinterpret_cast<const f16x8*>(qsrc + (4 * h2 + g) * 16);
+        ql[h2] = *reinterpret_cast<const f16x8*>(qsrc + 128 + (4 * h2 + g) * 16);
+    }
+
+    const int nkb = (T + AKB - 1) / AKB;
+    const int pr = lane >> 3, pos = lane & 7;
+    auto stage = [&](int buf, int kb) {
+        char* base = smem + buf * 4 * SIMG;
+        for (int p = wave; p < 32; p += nwaves) {                      // 4 images x 8 pieces of 8 rows
+            const int img = p >> 3, piece = p & 7;
+            const int r = piece * 8 + pr;
+            int gr = kb * AKB + r;
+            gr = gr < T ? gr : T - 1;                                  // rows past T re-read row T-1: finite, masked below
+            const int chunk = img < 2 ? (pos ^ ((r >> 1) & 7)) : ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1));
+            const char* src = (img < 2 ? kbase : vbase) + (size_t)gr * ldb + (img & 1) * 128 + chunk * 16;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + img * SIMG + piece * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+
+    float mrun = -INFINITY, lrun = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr float S_UNSCALE = 1.0f / (ATT_QS * ATT_KS);
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
+        __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
+        if (kb + 1 < nkb) stage((kb + 1) & 1, kb + 1);
+        if (active) {
+            const char* Kh = smem + (kb & 1) * 4 * SIMG;
+            const char* Kl = Kh + SIMG;
+            const char* Vh = Kl + SIMG;
+            const char* Vl = Vh + SIMG;
+            const int left = T - kb * AKB;
+            const int nkt = left >= AKB ? 4 : (left + 15) >> 4;       // key tiles with at least one real key (wave-uniform)
+            f32x4 s[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) { s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
+                }
+                s[kt] = acc * S_UNSCALE;
+            }
+            float bm = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
+                    bm = fmaxf(bm, s[kt][r]);
+                }
+            bm = xor16_max(bm);
+            bm = xor32_max(bm);
+            const float mnew = fmaxf(mrun, bm);
+            const float alpha = expf(mrun - mnew);
+            float psum = 0.f;
+            f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = expf(s[2 * grp + u][r] - mnew);
+                        psum += pv;
+                        const float x = pv * ATT_PS;
+                        const f16 h = (f16)x;
+                        ph[grp][4 * u + r] = h;
+                        pl[grp][4 * u + r] = (f16)(x - (float)h);
+                    }
+            lrun = lrun * alpha + psum;
+            mrun = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (2 * s2 >= nkt) continue;                          // both tiles of the group are padding
+                const int krow = 32 * s2 + 4 * g + (li >> 2);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int col = 16 * dt + 4 * (li & 3);
+                    union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
+                    uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
+                    uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
+                    ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
+                    ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    lrun = xor16_add(lrun);
+    lrun = xor32_add(lrun);
+    if (q < nq) {
+        float* row = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D;
+        const float inv = (1.0f / (ATT_VS * ATT_PS)) / lrun;          // (power of two) / l
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 v = (o[dt] * (1.0f / (ATT_VS * ATT_PS))) / lrun;
+            store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);
+        }
+        (void)inv;
+    }
+}
+
 }  // namespace
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
@@ -591,6 +771,19 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
     const int qblocks = (ntiles + nw - 1) / nw;
     const int64_t grid = (int64_t)n * n_heads * qblocks;
     if (grid > 0x7fffffff) return -1;
+    if (split_scale > 0.f) {                                // precision 4: q | k | v arrive split (store_head_split4)
+        static bool attr2 = false;
+        constexpr int lds2 = 2 * 4 * SIMG;
+        if (!attr2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds2) != hipSuccess)
+                return -2;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(attention_split_kernel, dim3((unsigned)grid), dim3(nw * 64), lds2, stream, qkv, q_cls, out, T, D, n_heads,
+                           qblocks, split_scale);
+        return CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks, split_scale);
     return CHECK_LAUNCH();
 }
