@@ -266,9 +266,12 @@ int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
 
 template <int EPI>
 int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
-    // (r4: a 256 x 128 tile with 8 waves and a 3-stage LDS ring - two K-tiles in flight under a counted vmcnt - was built for
-    //  the split form and measured: 9.90 ms per 64-frame ViT-B step against 9.35 ms with this two-buffer kernel at two
-    //  workgroups per CU; both run the split GEMMs at the fused fp16 kernel's rate, ~0.9 PF/s of executed MFMA work.  Removed.)
+    // (r4: two deeper-pipelined forms of the split GEMM were built and measured against this two-buffer kernel at two
+    //  workgroups per CU - a 256 x 128 tile, 8 waves, 3-stage LDS ring (two K-tiles in flight under a counted vmcnt): 9.90 ms
+    //  per 64-frame ViT-B step against 9.35; a 128 x 128 tile, 8 waves, 4-stage ring (three in flight): 9.90 against 8.70 on
+    //  another box, bit-identical results.  One workgroup per CU in barrier lockstep loses more than the extra K-tiles in
+    //  flight win; two independent workgroups fill each other's DMA waits.  PMC: matrix pipes 35-39 % busy at 2.2 GHz,
+    //  ~0.85 PF/s of executed MFMA work - the fused fp16 kernel's class.  Both removed.)
     return p.split ? launch_vit32s<EPI, true>(p, stream) : launch_vit32s<EPI, false>(p, stream);
 }
 

@@ -73,10 +73,9 @@ def test_vitl_cls_goldens(golden_dir, name, hw):
     n = int(g["n"])
     fr = synth.cage_frames(int(g["frame_seed"]), n, hw, hw)
     assert sha(fr) == str(g["frames_sha"])
-    if hw <= 256:                                  # numpy ViT-L: ~20 s per 224x224 frame, ~55 s per 518x518 frame: one small one
-        cls = PO.encode_frames(fr[:1], w, cfg, batch=1)
-        rel = np.linalg.norm(cls - g["cls"][:1], axis=1) / np.linalg.norm(g["cls"][:1], axis=1)
-        assert rel.max() < 2e-5, rel.max()
+    # (the numpy restatement costs ~20 s per 224x224 ViT-L frame and ~55 s per 518x518 one; it is pinned on the ViT-S / ViT-B
+    #  fixtures above - same code, other sizes - and the CPU suite has to stay within minutes: ViT-L goes through the torch
+    #  restatement of the same arithmetic only)
     # every golden frame through the torch restatement of the same arithmetic (oracle/vit_oracle_torch.py)
     from oracle import vit_oracle_torch as VT
     cls_t = VT.encode_frames(fr, VT.to_torch(w), cfg, batch=2)
@@ -150,10 +149,10 @@ def test_e2e_config1_golden(golden_dir):
     assert sha(fr) == str(g["frames_sha"])
     enc_w = W.synth_encoder_weights(cfg, 1234)
     head_w = W.synth_head_weights(C.HeadConfig(in_features=384), 4321)
-    # the numpy restatement on the first batch of 8, the torch restatement of the same arithmetic on all 64 frames
+    # the numpy restatement on the first 4 frames, the torch restatement of the same arithmetic on all 64 frames
     # (numpy ViT-S: ~2 s per frame)
-    first = PO.encode_frames(fr[:8], enc_w, cfg, batch=8)
-    rel16 = np.linalg.norm(first - g["cls"][:8], axis=1) / np.linalg.norm(g["cls"][:8], axis=1)
+    first = PO.encode_frames(fr[:4], enc_w, cfg, batch=4)
+    rel16 = np.linalg.norm(first - g["cls"][:4], axis=1) / np.linalg.norm(g["cls"][:4], axis=1)
     assert rel16.max() < 1e-5
     from oracle import vit_oracle_torch as VT
     cls32 = VT.encode_frames(fr, VT.to_torch(enc_w), cfg, batch=8)
