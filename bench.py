@@ -94,6 +94,18 @@ def cpu_baseline(model: str, hw: int, frames: int, batch: int) -> dict:
                       f"restatement of the encoder (oracle/vit_oracle_torch.py) + numpy LSTM head), {dt:.1f} s wall"}
 
 
+_FRAME_CACHE: dict = {}
+
+
+def _frames(kind: str, seed: int, n: int, hw: int, first: int = 0):
+    """Synthetic fixture frames, generated once per process (the label-exact leg reuses what the default leg made)."""
+    key = (kind, seed, n, hw, first)
+    if key not in _FRAME_CACHE:
+        mk = synth.noise_frames if kind == "noise" else synth.cage_frames
+        _FRAME_CACHE[key] = mk(seed, n, hw, hw, first=first)
+    return _FRAME_CACHE[key]
+
+
 def gates(enc, head, model: str, hw: int, precision: int) -> dict:
     """SURVEY section 8(d) 'correctness gates reported with every number', against fixtures generated from the
     reference (tests/golden/make_goldens.py): max per-frame ||CLS - ref||2 / ||ref||2 on the golden frames of this
@@ -105,8 +117,7 @@ def gates(enc, head, model: str, hw: int, precision: int) -> dict:
     path = os.path.join(gd, f"{name}.npz") if name else None
     if path and os.path.exists(path):
         g = np.load(path)
-        mk = synth.noise_frames if str(g["kind"]) == "noise" else synth.cage_frames
-        fr = mk(int(g["frame_seed"]), int(g["n"]), hw, hw)
+        fr = _frames("noise" if str(g["kind"]) == "noise" else "cage", int(g["frame_seed"]), int(g["n"]), hw)
         _, c32 = enc.encode_u8(torch.from_numpy(fr).to(enc.device))
         c32 = c32.cpu().numpy().astype(np.float64)
         ref = g["cls"].astype(np.float64)
@@ -127,7 +138,7 @@ def gates(enc, head, model: str, hw: int, precision: int) -> dict:
     ep = os.path.join(gd, "e2e_vitb16.npz")
     if os.path.exists(ep) and (model, hw) == ("vitb16", 224) and head.in_features == 768 and head.out_features == BEHAVIORS:
         g = np.load(ep)
-        fr = synth.cage_frames(int(g["frame_seed"]), int(g["n"]), hw, hw)
+        fr = _frames("cage", int(g["frame_seed"]), int(g["n"]), hw)
         c16, _ = enc.encode_u8(torch.from_numpy(fr).to(enc.device), want_f32=False)
         pr = head.infer_clip(c16, 1.0).cpu().numpy().astype(np.float64)
         ref = g["probs"].astype(np.float64)
@@ -150,7 +161,7 @@ def gates(enc, head, model: str, hw: int, precision: int) -> dict:
         n = int(g["n"])
         c16 = torch.empty((n, 768), dtype=torch.float16, device=enc.device)
         for i in range(0, n, 512):
-            fr = synth.cage_frames(int(g["frame_seed"]), min(512, n - i), hw, hw, first=i)
+            fr = _frames("cage", int(g["frame_seed"]), min(512, n - i), hw, first=i)
             c16[i:i + len(fr)] = enc.encode_u8(torch.from_numpy(fr).to(enc.device), want_f32=False)[0]
         pr = head.infer_clip(c16, 1.0).cpu().numpy().astype(np.float64)
         ref = g["probs"].astype(np.float64)
@@ -257,6 +268,9 @@ def main() -> None:
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-gates", action="store_true")
+    ap.add_argument("--no-label-exact", action="store_true",
+                    help="skip the secondary leg that runs the same clip in precision 4 (the label-exact mode) and reports its "
+                         "frames/s and gates beside the default mode's")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (compute lanes of the encoder)")
     ap.add_argument("--files", type=int, default=2, help="clips per rank of the files_path pass (0: skip it)")
     ap.add_argument("--clip-frames", type=int, default=4096, help="frames per clip of the files_path pass")
@@ -565,6 +579,43 @@ def main() -> None:
         out["files_path"] = files
     if not args.no_gates and not hung:
         out["gates"] = gates(enc, head, args.model, args.hw, args.precision)
+    # Secondary leg, N = 1 only: the SAME model, head and clip through precision 4 - fp32 storage / attention / LayerNorm with
+    # the GEMM products as three-term fp16 splits - the mode whose argmax labels are the reference's.  `value`
+    # above stays the default fp16-operand mode's, as BASELINE.json's config asks; this says what label identity costs.
+    if (world == 1 and args.precision == 0 and not args.no_label_exact and not args.no_gates and not hung
+            and (args.model, args.hw) == ("vitb16", 224)):
+        enc4 = None
+        try:
+            enc4 = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), device, max_batch=B,
+                                            max_frame=(args.hw, args.hw), precision=4)
+            enc4.set_lanes(args.lanes)
+            k4 = min(K, 40)
+            st4 = ClipStream(enc4, head, capacity=k4 * B, classify_every=1024)
+
+            def run4():
+                st4.reset()
+                for s_ in range(k4):
+                    o = (s_ * B) % n_res
+                    st4.push_u8(clip[o:o + B])
+                return st4.finish()
+            run4()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            run4()
+            torch.cuda.synchronize(device)
+            dt4 = time.perf_counter() - t0
+            st4.close()
+            out["label_exact"] = {"precision": 4, "value": round(k4 * B / dt4, 2), "unit": "frames/s", "steps": k4,
+                                  "ms_per_step": round(dt4 / k4 * 1e3, 4),
+                                  "what": "the same model, head and clip (frames resident in HBM) in precision 4: fp32 storage, attention, "
+                                          "LayerNorm; GEMM and attention products on the fp16 matrix pipe from operands split into "
+                                          "two fp16 halves; one untimed pass, then k steps timed",
+                                  "gates": gates(enc4, head, args.model, args.hw, 4)}
+        except Exception as e:  # noqa: BLE001 - the headline line must not depend on the secondary leg
+            out["label_exact"] = {"precision": 4, "error": f"{type(e).__name__}: {e}"}
+        finally:
+            if enc4 is not None:
+                enc4.close()
     if prof:
         gemm = [k for k in prof if k.endswith("_gemm")]
         g_ms = sum(prof[k]["ms"] for k in gemm)

@@ -543,6 +543,18 @@ __device__ __forceinline__ int sv_off(int row, int col) {   // col in halves
 }
 constexpr int SIMG = AKB * 128;             // bytes of one hi or lo image of a 64-key block
 
+// exp(x) for x <= 0 (softmax arguments), 7 VALU instructions against the device library's 13 (no overflow / underflow
+// branches: the argument is clamped at -100, where v_exp_f32 flushes to 0): exp2 of the rounded product x log2(e), corrected
+// by the product's exact rounding residual and the low part of log2(e) - as accurate as expf (v_exp_f32 is 1 ulp).
+__device__ __forceinline__ float exp_neg(float x) {
+    const float v = fmaxf(x, -100.f);
+    const float t = v * 1.44269504f;
+    float r = fmaf(v, 1.44269504f, -t);
+    r = fmaf(v, 1.92596299e-8f, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147181f, e);
+}
+
 __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                  float* __restrict__ out, int T, int D, int n_heads, int qblocks,
                                                                  float out_scale) {
@@ -617,18 +629,22 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
                 }
                 s[kt] = acc * S_UNSCALE;
             }
+            if (kb == nkb - 1) {                                      // only the last block can hold keys past T (scalar branch)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
+            }
             float bm = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
-                    bm = fmaxf(bm, s[kt][r]);
-                }
+                for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
             bm = xor16_max(bm);
             bm = xor32_max(bm);
             const float mnew = fmaxf(mrun, bm);
-            const float alpha = expf(mrun - mnew);
+            const float alpha = exp_neg(mrun - mnew);
             float psum = 0.f;
             f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
 #pragma unroll
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = expf(s[2 * grp + u][r] - mnew);
+                        const float pv = exp_neg(s[2 * grp + u][r] - mnew);
                         psum += pv;
                         const float x = pv * ATT_PS;
                         const f16 h = (f16)x;
