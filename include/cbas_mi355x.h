@@ -93,7 +93,11 @@ typedef struct cbas_enc_config {
                                         the weight packer), a w ~ a_hi w_hi + a_hi w_lo + a_lo w_hi on
                                         v_mfma_f32_16x16x32_f16 with fp32 accumulation.  CLS rows are as close to the
                                         reference as precision 3's (measured: slightly closer - the MFMA sums each block of 32
-                                        products before rounding into the accumulator); twice its frame rate. */
+                                        products before rounding into the accumulator); 2.4x its frame rate.  The split
+                                        halves are fp16: after the fixed power-of-two scales an activation must stay below
+                                        65 504 - LayerNorm rows as they are, |attention context| and |q| / 8 < 4 094, |k|, |v|
+                                        and |GELU output| < 16 376 (far above what ViT checkpoints with "massive activation"
+                                        channels produce: tests/test_gpu_fp32.py); precision 3 has no such bound. */
     int32_t use_rope;             /* 1: DINOv3 (RoPE on patch rows, no additive position embedding)     */
     int32_t pos_embed_grid;       /* G > 0: DINOv2-with-registers, learned (1+G*G, D) position embedding,
                                      bicubic-antialias interpolated to each frame's patch grid; else 0 */

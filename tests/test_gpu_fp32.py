@@ -291,3 +291,35 @@ def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, 
         assert open(out, "rb").read() == open(h5b, "rb").read() and open(csv, "rb").read() == open(csvb, "rb").read()
     finally:
         enc.close(); head.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_massive_activation_channels(precision):
+    """What real checkpoints do and random weights do not: residual-stream channels hundreds of times larger than the rest,
+    20x register tokens, 5x LayerNorm gains on the hot channels (the construction of test_gpu_parity.py's fp16 test).
+    Precision 3 keeps everything fp32; precision 4 splits LayerNorm rows, attention context, GELU output, q, k, v and the
+    probabilities into fp16 halves after power-of-two scaling - the hot channels must neither overflow fp16 (65 504) nor
+    push the small ones' low halves into precision loss that shows: CLS within 5e-6 of the fp32 oracle in both modes."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.NAMED_VIT["vits16"]
+    w = {k: v.copy() for k, v in W.synth_encoder_weights(cfg, 1234).items()}
+    for l, sign, hot in ((2, 1.0, [7, 100, 300]), (5, -1.0, [11, 200, 350])):
+        w[f"model.layer.{l}.mlp.down_proj.bias"][hot] += sign * 80.0 / np.abs(w[f"model.layer.{l}.layer_scale2.lambda1"][hot])
+        for n in ("norm1", "norm2"):
+            w[f"model.layer.{l + 1}.{n}.weight"][hot] *= 5.0
+    w["embeddings.register_tokens"] = w["embeddings.register_tokens"] * 20.0
+    fr = synth.cage_frames(5, 4, 224, 224)
+    ref = PO.encode_frames(fr, w, cfg, batch=4)
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=4, max_frame=(224, 224), precision=precision)
+    try:
+        _, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+        tap = enc.debug_tap(torch.from_numpy(fr).cuda(), 6, 7, 0)          # residual stream after block 6 (fp32 in both modes)
+        torch.cuda.synchronize()
+        assert np.abs(tap).max() > 60.0                                    # the outliers are really there
+        assert torch.isfinite(c32).all()
+        r = rel_rows(c32.cpu().numpy(), ref)
+        print(f"[precision {precision} massive activations] CLS rel err max {r.max():.3e}")
+        assert r.max() < CLS_TOL_F32, r.max()
+    finally:
+        enc.close()
