@@ -11,6 +11,8 @@ through pinned staging with copy/compute overlap.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
@@ -58,12 +60,20 @@ class DinoEncoder:
     """MI355X DINOv3 ViT encoder behind the reference's ``DinoEncoder`` interface."""
 
     def __init__(self, model_identifier: str, device="cuda", max_batch: int = 128,
-                 max_frame: Tuple[int, int] = (256, 256), precision: int = 0):
+                 max_frame: Tuple[int, int] = (256, 256), precision: Optional[int] = None):
         # max_batch: frames per encoder launch sequence.  A frame's row does not depend on its batch (bit-exact:
         # tests/test_gpu_parity.py::test_vitb_full_batch_invariance), so this is scheduling only: 128 runs the file path
         # ~3 % faster than 64 (fewer partly-filled tile rounds per frame; 256 adds nothing) for ~1 GB more workspace.
         ckpt = find_checkpoint_dir(model_identifier)
         cfg, weights = load_encoder_checkpoint(ckpt)
+        if precision is None:
+            # CBAS constructs the encoder as DinoEncoder(model_identifier=..., device=...) (startup_page.py:66-69): the
+            # arithmetic mode of an unmodified checkout is chosen through the environment.  0 = fp16 operands (fastest),
+            # 4 = the label-exact mode (include/cbas_mi355x.h).  MX-fp8 (2) is refused here: its rows need their own heads.
+            precision = int(os.environ.get("CBAS_PRECISION", "0"))
+            if precision == 2:
+                raise ValueError("CBAS_PRECISION=2 (MX-fp8) is not selectable through the environment: its rows are not "
+                                 "interchangeable with the other modes' (pass precision=2 explicitly)")
         self._init(cfg, weights, device, max_batch, max_frame, precision)
         self.model_identifier = model_identifier
 

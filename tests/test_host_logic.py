@@ -108,6 +108,24 @@ def test_create_rejects_bad_arguments_without_gpu():
     assert lib.cbas_head_infer_f16(None, None, 1, 1.0, None, None, None) == -1
 
 
+def test_precision_argument_checks_without_gpu(tmp_path, monkeypatch):
+    """precision outside 0..4 is refused by the library before anything touches a device; the reference-style constructor
+    takes its mode from CBAS_PRECISION and refuses MX-fp8 there (its rows need their own heads)."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    dummy = np.zeros(4, np.float32)
+    for bad in (-1, 5):
+        cc = _lib.EncConfig(128, 512, 2, 2, 4, 16, 1e-5, 100.0, 8, 64, 64, bad, 1, 0)
+        rc = lib.cbas_enc_create(C.byref(cc), dummy.ctypes.data, 4, 0, C.byref(h))
+        assert rc == -1 and b"precision" in lib.cbas_last_error()
+    from cbas_amd.encoder import DinoEncoder
+    ck = str(tmp_path / "ck")
+    W.save_encoder_checkpoint(ck, Cfg.VIT_TINY, W.synth_encoder_weights(Cfg.VIT_TINY, 3))
+    monkeypatch.setenv("CBAS_PRECISION", "2")
+    with pytest.raises(ValueError, match="MX-fp8"):
+        DinoEncoder(ck, device="cuda")
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
