@@ -20,6 +20,7 @@
 //
 // The matrix pipe runs at 1/16 of the fp16 rate here (157 TFLOP/s peak), so the GEMM is MFMA-bound by a wide margin
 // and the geometry is the simple one of gemm_f32.hip: 128x128 tiles, 4 waves, two LDS buffers, LDS-DMA staging.
+#include <stdlib.h>
 #include "kernels.h"
 #include "gemm_f32_tile.h"
 
@@ -248,6 +249,124 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_vit_kernel(Gemm32VitParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// precision 4, large M.  The split loop is 48 MFMAs (768 cycles) per K-tile and wave: the kernel above, 4 waves per
+// workgroup, spends most of a K-tile waiting for the LDS-DMA round trip of the one K-tile it has in flight (PMC: matrix
+// pipes 35-39 % busy at 2.2 GHz).  What helped, measured (ViT-B/16 batch 64, ms per step, same device, bit-identical
+// results): more waves per CU - THIS form: the same 128 x 128 tile and two LDS buffers, hence still two workgroups per CU,
+// but 8 waves as 4 (M) x 2 (N) with 32 x 64 per wave (a 64-column group per wave: the RoPE partner stays in the lane), one
+// raw s_barrier per K-tile: 7.64 against 7.96.  What did not: more K-tiles in flight at one workgroup per CU - a
+// 256 x 128 tile with a 3-stage ring: 9.90 against 9.35; this tile with a 4-stage ring (three in flight, counted vmcnt):
+// 9.90 against 8.70 - a single workgroup in barrier lockstep loses more than the deeper prefetch wins.
+//   iteration kt:  wait own pieces of tile kt (vmcnt 0) -> barrier (everybody's pieces landed AND everybody is past its
+//                  reads of tile kt-1) -> issue tile kt+1 into tile kt-1's buffer -> 12 fragment reads + 24 MFMAs
+// Same products in the same order per output element as the 4-wave kernel: bit-identical results, so the choice by M
+// keeps batch invariance exact.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int S8_STAGES = 2;
+
+__device__ __forceinline__ void stage_half8(const float* __restrict__ g, int64_t ld, int64_t row0, int64_t max_row, int k0,
+                                            char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                          // 128 rows = 16 pieces of 8 rows over 8 waves
+        const int piece = wave * 2 + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t row = row0 + r;
+        row = row < max_row ? row : max_row;
+        const float* src = g + row * ld + k0 + chunk * 4;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_split8_kernel(Gemm32VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 2 * TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = p.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int col0 = tn * BN;
+    const int nk = p.K / BKF;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE;
+        stage_half8(p.A, p.lda, row0, p.M - 1, kt * BKF, base, wave, lane);
+        stage_half8(p.W, p.K, col0, p.N - 1, kt * BKF, base + TILE_BYTES, wave, lane);
+    };
+    stage(0, 0);
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int cur = 0, nxt = 1;                                   // buffer of tile kt / of tile kt + 1
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage(nxt, kt + 1);
+        const char* At = smem + cur * STAGE;
+        const char* Wt = At + TILE_BYTES;
+        f16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = __builtin_bit_cast(f16x8, read_frag32(At, wr * 32 + i * 16 + frow, fchunk));
+            al[i] = __builtin_bit_cast(f16x8, read_frag32(At, wr * 32 + i * 16 + frow, 4 + fchunk));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = __builtin_bit_cast(f16x8, read_frag32(Wt, wc * 64 + j * 16 + frow, fchunk));
+            bl[j] = __builtin_bit_cast(f16x8, read_frag32(Wt, wc * 64 + j * 16 + frow, 4 + fchunk));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            }
+        cur ^= 1;
+        nxt ^= 1;
+    }
+
+    const float unscale = 1.0f / (p.a_scale * p.w_scale);     // powers of two: exact
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= unscale;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = row0 + wr * 32 + i * 16 + (lane & 15);
+        if (m < p.M) vit32_epilogue_row<EPI>(p, (int)m, col0 + wc * 64, lane, acc[i]);
+    }
+}
+
+template <int EPI>
+int launch_split8(const Gemm32VitParams& p, hipStream_t stream) {
+    constexpr int lds = S8_STAGES * 2 * TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split8_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const int64_t grid = ((int64_t)(p.M + BM - 1) / BM) * (p.N / BN);
+    if (grid <= 0 || grid > 0x7fffffff) return -1;
+    hipLaunchKernelGGL((gemm_split8_kernel<EPI>), dim3((unsigned)grid), dim3(512), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int EPI, bool SPLIT>
 int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
     constexpr int lds = 4 * TILE_BYTES;
@@ -266,13 +385,8 @@ int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
 
 template <int EPI>
 int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
-    // (r4: two deeper-pipelined forms of the split GEMM were built and measured against this two-buffer kernel at two
-    //  workgroups per CU - a 256 x 128 tile, 8 waves, 3-stage LDS ring (two K-tiles in flight under a counted vmcnt): 9.90 ms
-    //  per 64-frame ViT-B step against 9.35; a 128 x 128 tile, 8 waves, 4-stage ring (three in flight): 9.90 against 8.70 on
-    //  another box, bit-identical results.  One workgroup per CU in barrier lockstep loses more than the extra K-tiles in
-    //  flight win; two independent workgroups fill each other's DMA waits.  PMC: matrix pipes 35-39 % busy at 2.2 GHz,
-    //  ~0.85 PF/s of executed MFMA work - the fused fp16 kernel's class.  Both removed.)
-    return p.split ? launch_vit32s<EPI, true>(p, stream) : launch_vit32s<EPI, false>(p, stream);
+    if (!p.split) return launch_vit32s<EPI, false>(p, stream);
+    return p.M > 256 ? launch_split8<EPI>(p, stream) : launch_vit32s<EPI, true>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
