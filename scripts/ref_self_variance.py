@@ -51,15 +51,17 @@ def main():
     if len(sys.argv) > 2:
         n = min(n, int(sys.argv[2]))
     cbas, classifier_head = MG.import_reference()
-    cfg = C.VIT_B16
-    frames = synth.cage_frames(int(g["frame_seed"]), n, 224, 224)
+    dinov2 = fixture.startswith("e2e_dinov2")
+    cfg = C.DINOV2_REG_B14 if dinov2 else C.VIT_B16
+    hw = int(g["hw"]) if "hw" in g.files else 224
+    frames = synth.cage_frames(int(g["frame_seed"]), n, hw, hw)
     os.replace = MG._real_replace
     ref_probs = g["probs"][:n].astype(np.float64)
     srt = np.sort(ref_probs, axis=1)
     margins = srt[:, -1] - srt[:, -2]
     out = {"fixture": fixture, "frames": n, "variants": []}
     with tempfile.TemporaryDirectory() as td:
-        MG.hf_model(cfg, W.synth_encoder_weights(cfg, MG.ENC_SEED)).save_pretrained(td)
+        (MG.hf_dinov2 if dinov2 else MG.hf_model)(cfg, W.synth_encoder_weights(cfg, MG.ENC_SEED)).save_pretrained(td)
         enc = cbas.DinoEncoder(td, device="cpu")
         hcfg = C.HeadConfig(in_features=768)
         hm = MG.ref_head(classifier_head, hcfg, W.synth_head_weights(hcfg, MG.HEAD_SEED))

@@ -598,8 +598,42 @@ def g_dinov2(out):
     print("dinov2", cls224.shape, cls256.shape)
 
 
+def g_e2e_dinov2(out):
+    """CBAS's DEFAULT encoder family end to end (r4): DINOv2-with-registers ViT-B/14 (backend/cbas.py:1030-1033) through the
+    reference's own DinoEncoder wrapper at CBAS's standard 256 x 256 video size (18 x 18 patches, T = 329), 512 frames in
+    8-frame calls -> f16 -> the reference's infer_file, C = 9.  Stored like the long DINOv3 fixture: f16 rows for every frame,
+    f32 CLS for every 8th, probabilities, labels."""
+    cbas, classifier_head = import_reference()
+    cfg = C.DINOV2_REG_B14
+    w = W.synth_encoder_weights(cfg, ENC_SEED)
+    n = 512
+    frames = synth.cage_frames(8, n, 256, 256)
+    os.replace = _real_replace
+    with tempfile.TemporaryDirectory() as td:
+        hf_dinov2(cfg, w).save_pretrained(td)
+        enc = cbas.DinoEncoder(td, device="cpu")
+        g = torch.from_numpy(frames[:, :, :, 1] / 255.0).float()
+        cls = torch.cat([enc(g[i:i + 8].unsqueeze(1)).squeeze(1) for i in range(0, n, 8)]).numpy()
+        hcfg = C.HeadConfig(in_features=768)
+        hm = ref_head(classifier_head, hcfg, W.synth_head_weights(hcfg, HEAD_SEED))
+        p = os.path.join(td, "e2e_cls.h5")
+        with _FakeH5File(p, "w") as f:
+            d = f.create_dataset("cls", shape=(n, 768), dtype="f2")
+            d[:] = cls
+            cls16 = d[:].copy()
+        o = cbas.infer_file(p, hm, "gold", BEHAVIORS, 31, device=torch.device("cpu"), temperature=1.0)
+        import pandas as pd
+        probs = pd.read_csv(o).to_numpy(dtype=np.float64).astype(np.float32)
+    labels = probs.argmax(1)
+    np.savez_compressed(os.path.join(out, "e2e_dinov2reg_b14.npz"), cls_every8=cls[::8].astype(np.float32), cls_f16=cls16,
+                        probs=probs, labels=labels, frames_sha=sha(frames), frame_seed=8, n=n, hw=256)
+    top2 = np.sort(probs, axis=1)[:, -2:]
+    print("e2e dinov2 labels", np.bincount(labels, minlength=9), "transitions", int((labels[1:] != labels[:-1]).sum()),
+          "smallest top-2 margins", np.sort(top2[:, 1] - top2[:, 0])[:8])
+
+
 ALL = {"dinov2": g_dinov2, "tiny": g_tiny, "vits": g_vits, "vitb": g_vitb, "vitb_noise": g_vitb_noise, "vitb256": g_vitb256,
-       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_variants": g_head_variants, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e, "e2e_vitb": g_e2e_vitb, "e2e_vitb_long": g_e2e_vitb_long,
+       "vitl": g_vitl, "vitl518": g_vitl518, "head": g_head, "head_variants": g_head_variants, "head_train": g_head_train, "infer": g_infer, "e2e": g_e2e, "e2e_vitb": g_e2e_vitb, "e2e_vitb_long": g_e2e_vitb_long, "e2e_dinov2": g_e2e_dinov2,
        "encode_file": g_encode_file}
 
 if __name__ == "__main__":

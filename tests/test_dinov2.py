@@ -108,3 +108,23 @@ def test_gpu_b14_goldens(golden_dir, tmp_path):
             assert r.max() < 1e-3, (hw, r.max())
     finally:
         enc.close()
+
+
+def test_oracle_e2e_default_encoder_fixture(golden_dir):
+    """The end-to-end fixture of CBAS's default encoder family (tests/golden/e2e_dinov2reg_b14.npz: the reference's own
+    DinoEncoder wrapper on DINOv2-with-registers B/14 at 256 x 256 + its infer_file): the numpy restatement reproduces the
+    f32 CLS of sampled frames, and the head restatement reproduces every label from the reference's own f16 rows."""
+    from oracle import pipeline_oracle as PO
+    g = np.load(os.path.join(golden_dir, "e2e_dinov2reg_b14.npz"))
+    cfg = C.DINOV2_REG_B14
+    n, hw = int(g["n"]), int(g["hw"])
+    w = W.canonical_encoder_weights(cfg, W.synth_encoder_weights(cfg, 1234))
+    pick = [0, 8 * 31]
+    fr = np.concatenate([synth.cage_frames(int(g["frame_seed"]), 1, hw, hw, first=i) for i in pick])
+    px = np.repeat(V.preprocess_green(fr)[:, None], 3, 1)
+    cls = O.forward(px, w, cfg)[:, 0]
+    assert rel_rows(cls, g["cls_every8"][[p // 8 for p in pick]]).max() < 2e-5
+    assert np.array_equal(g["cls_every8"].astype(np.float16), g["cls_f16"][::8])          # the f4 -> f2 store, cbas.py:438
+    probs = PO.classify_cls(g["cls_f16"], W.synth_head_weights(C.HeadConfig(in_features=768), 4321), 31, 1.0)
+    np.testing.assert_allclose(probs, g["probs"], atol=1e-5)
+    assert (probs.argmax(1) == g["labels"]).all() and len(set(g["labels"].tolist())) >= 2

@@ -152,8 +152,9 @@ def _e2e(golden_dir, name, cfg, dim, batch, precision=3):
     from cbas_amd.stream import ClipStream
     g = load(golden_dir, name)
     n = int(g["n"])
-    fr = synth.cage_frames(int(g["frame_seed"]), n, 224, 224)
-    enc = make_enc(cfg, 224, batch, precision)
+    hw = int(g["hw"]) if "hw" in g.files else 224
+    fr = synth.cage_frames(int(g["frame_seed"]), n, hw, hw)
+    enc = make_enc(cfg, hw, batch, precision)
     head = make_head(dim)
     try:
         st = ClipStream(enc, head, capacity=n)
@@ -323,3 +324,14 @@ def test_fp32_massive_activation_channels(precision):
         assert r.max() < CLS_TOL_F32, r.max()
     finally:
         enc.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fp32_e2e_dinov2_default_encoder_labels_identical(golden_dir, precision):
+    """CBAS's DEFAULT encoder family end to end: DINOv2-with-registers ViT-B/14 through the reference's own DinoEncoder
+    wrapper at 256 x 256 (T = 329), 512 frames, then the reference's infer_file (tests/golden/e2e_dinov2reg_b14.npz): every
+    label identical - or one of the reference's own variants' labels for that frame (two frames of this clip have reference
+    top-2 margins of 1.3e-4 and 9.4e-4)."""
+    g, cls16, probs = _e2e(golden_dir, "e2e_dinov2reg_b14", C.DINOV2_REG_B14, 768, 32, precision)
+    _strict_gate(golden_dir, f"precision {precision} e2e_dinov2reg_b14", "e2e_dinov2reg_b14", g, cls16, probs, g["cls_every8"],
+                 slice(0, None, 8))

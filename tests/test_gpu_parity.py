@@ -338,6 +338,37 @@ def test_e2e_long_clip_flip_rate_fp16(golden_dir):
         enc.close(); head.close()
 
 
+def test_e2e_dinov2_default_encoder_flip_rate_fp16(golden_dir):
+    """The default fp16-operand mode on CBAS's DEFAULT encoder family (DINOv2-with-registers ViT-B/14, 256 x 256, 512 frames;
+    tests/golden/e2e_dinov2reg_b14.npz = the reference's own wrapper + infer_file): CLS within the 1e-3 contract, no flip at a
+    reference margin >= conftest.MARGIN_FP16, at most 1 % of the labels differ."""
+    from cbas_amd.encoder import DinoEncoder
+    from cbas_amd.head import ClassifierLSTMDeltas
+    from cbas_amd.stream import ClipStream
+    g = load(golden_dir, "e2e_dinov2reg_b14")
+    n, hw = int(g["n"]), int(g["hw"])
+    cfg = C.DINOV2_REG_B14
+    fr = synth.cage_frames(int(g["frame_seed"]), n, hw, hw)
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=32, max_frame=(hw, hw))
+    head = ClassifierLSTMDeltas(768, 9)
+    head.load_state_dict(W.synth_head_weights(C.HeadConfig(in_features=768), 4321))
+    head.to("cuda")
+    try:
+        st = ClipStream(enc, head, capacity=n)
+        for i in range(0, n, 32):
+            st.push_u8(torch.from_numpy(fr[i:i + 32]).cuda())
+        cls16, probs = st.finish()
+        torch.cuda.synchronize()
+        probs = probs.cpu().numpy()
+        r = rel_rows(cls16.float().cpu().numpy()[::8], g["cls_every8"])
+        n_mis, _ = assert_labels_match(probs, g["probs"], 5e-2)
+        print(f"[e2e_dinov2reg_b14 fp16] {n_mis} of {n} labels differ; CLS rel err max {r.max():.3e}")
+        assert r.max() < CLS_TOL + 5e-4
+        assert n_mis <= max(2, n // 100)
+    finally:
+        enc.close(); head.close()
+
+
 def test_encode_file_and_infer_file_dropins(golden_dir, tmp_path):
     """The file-level drop-ins on a synthetic 'video': chunk loop with a ragged tail, progress
     callback values, .tmp + rename, h5 stamp, CSV name/header; CLS vs the reference's encode_file."""
