@@ -1356,6 +1356,78 @@ __global__ void checksum_u16(const uint16_t* p, int64_t n, unsigned long long* o
 }
 }  // namespace
 
+// precision-4 GEMM (split operands) alone: epi = 1 q|k|v (RoPE), 2 residual, 3 GELU; tile = 0 (planner) / 128 / 160 / 192 / 256
+// rows of the ping-pong form, -1 = the 128 x 128 8-wave kernel; prints the block timeline.  Timing only (random operands).
+extern "C" int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int tile, int iters, float* ms_out) {
+    if (M <= 256 || N % 256 || K % 64 || iters <= 0 || epi < 1 || epi > 3) return cbas_fail(CBAS_EINVAL, "bad split GEMM bench shape");
+    if (epi == 1 && (N % 3 || (N / 3) % 64)) return cbas_fail(CBAS_EINVAL, "q|k|v bench needs N = 3 D, D a multiple of 64");
+    float *A = nullptr, *Wt = nullptr, *out = nullptr, *bias = nullptr, *rope = nullptr;
+    HIP_TRY(hipMalloc(&A, (int64_t)M * K * 4));
+    HIP_TRY(hipMalloc(&Wt, (int64_t)N * K * 4));
+    HIP_TRY(hipMalloc(&out, (int64_t)M * N * 4));
+    HIP_TRY(hipMalloc(&bias, (int64_t)N * 4));
+    HIP_TRY(hipMalloc(&rope, 2 * 196 * 64 * 4));
+    HIP_TRY(hipMemset(bias, 0, (int64_t)N * 4));
+    HIP_TRY(hipMemset(out, 0, (int64_t)M * N * 4));
+    HIP_TRY(hipMemset(rope, 0, 2 * 196 * 64 * 4));
+    hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)(((int64_t)M * K * 2 + 255) / 256)), dim3(256), 0, 0, (f16*)A, (int64_t)M * K * 2, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)(((int64_t)N * K * 2 + 255) / 256)), dim3(256), 0, 0, (f16*)Wt, (int64_t)N * K * 2, 2u, 0.05f);
+    Gemm32VitParams p{};
+    p.A = A; p.lda = K; p.W = Wt; p.M = M; p.N = N; p.K = K; p.bias = bias; p.lambda = bias; p.out = out; p.ldo = N;
+    p.tokens_per_frame = 201; p.n_prefix = 5; p.patches_per_frame = 196; p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3;
+    p.split = 1; p.a_scale = 1.f; p.w_scale = 1.f; p.out_scale = 1.f;
+    const GemmEpilogue e = (GemmEpilogue)epi;
+    auto run = [&]() { return tile < 0 ? launch_gemm_f32_vit(e, p, 0) : launch_gemm_split_pp(e, p, 0); };
+    if (tile < 0) setenv("CBAS_SPLIT_PP", "0", 1);
+    gemm_split_pp_debug(tile > 0 ? tile : 0, nullptr);
+    int rc = run();
+    if (rc) return cbas_fail(CBAS_EINVAL, "split GEMM launch failed (rc=%d)", rc);
+    HIP_TRY(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) run();
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    if (tile >= 0) {
+        const int nblk = GEMM_STAMP_BLOCKS;
+        unsigned long long* st = nullptr;
+        HIP_TRY(hipMalloc(&st, (size_t)nblk * 72));
+        HIP_TRY(hipMemset(st, 0, (size_t)nblk * 72));
+        gemm_split_pp_debug(tile > 0 ? tile : 0, st);
+        run();
+        HIP_TRY(hipDeviceSynchronize());
+        gemm_split_pp_debug(0, nullptr);
+        std::vector<unsigned long long> hs((size_t)nblk * 9);
+        HIP_TRY(hipMemcpy(hs.data(), st, (size_t)nblk * 72, hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi_c = 0, real = 0; int n = 0;
+        for (int b = 0; b < nblk; ++b) {
+            if (!hs[4 * b + 3]) continue;
+            pro += (double)(hs[4 * b + 1] - hs[4 * b]); loop += (double)(hs[4 * b + 2] - hs[4 * b + 1]);
+            epi_c += (double)(hs[4 * b + 3] - hs[4 * b + 2]); real += (double)hs[(size_t)nblk * 4 + b]; ++n;
+        }
+        if (n) printf("  stamps (first tile of each workgroup): %d workgroups; avg prologue %.0f, K loop %.0f (%.0f per K-tile), epilogue %.0f cycles; "
+                      "in-kernel clock %.2f GHz\n", n, pro / n, loop / n, loop / n / (K / 32), epi_c / n, real > 0 ? loop / real * 0.1 : 0.0);
+        double lp = 0, ll = 0, le = 0; int ln = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned long long* o = &hs[(size_t)nblk * 5 + 4 * (size_t)b];
+            if (!o[3]) continue;
+            lp += (double)(o[1] - o[0]); ll += (double)(o[2] - o[1]); le += (double)(o[3] - o[2]); ++ln;
+        }
+        if (ln) printf("  last tile of the %d workgroups that ran more than one: prologue %.0f, K loop %.0f, epilogue %.0f cycles\n",
+                       ln, lp / ln, ll / ln, le / ln);
+        fflush(stdout);
+        hipFree(st);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(A); hipFree(Wt); hipFree(out); hipFree(bias); hipFree(rope);
+    return CBAS_OK;
+}
+
 extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
                                      unsigned long long* checksum_out) {
     // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100;

@@ -47,6 +47,7 @@
 #include <type_traits>
 #include <vector>
 #include "gemm_epilogue.h"
+#include "vit32_epilogue.h"
 
 namespace {
 
@@ -80,9 +81,10 @@ constexpr int pp_lds_kernel() {
 // Runs the tiles `first, first + stride, ...` (< n_kind) of one kind: tile id -> (tm, tn) through the XCD remap over
 // n_kind ids; rows start at base_row.  Persistent: while a tile's epilogue runs, the LDS-DMA of the NEXT tile's first
 // K-tile is already in flight into buffer 0 (its latency - most of the prologue - hides under the epilogue).
-template <int EPI, int TA, int TB, bool F8>
+template <int EPI, int TA, int TB, bool F8, bool SPLIT = false, typename SP = int>
 __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int first, int n_kind, int stride, int base_row,
-                                         int tiles_n, const float* rope_lds, char* ln_lds) {
+                                         int tiles_n, const float* rope_lds, char* ln_lds, const SP& sp = SP()) {
+    static_assert(!(F8 && SPLIT), "one operand form at a time");
     constexpr int TM = TA + TB;                      // 16-row MFMA tiles per wave
     constexpr int WROWS = 16 * TM;                   // rows of C per wave
     constexpr int BM = 2 * WROWS;
@@ -97,14 +99,14 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
     int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int nk = p.K / (F8 ? 2 * BK : BK);           // even, >= 2 (checked by the launcher)
-    constexpr int ESZ = F8 ? 1 : 2;                    // bytes per operand element: a K-tile is always 128 bytes per row
+    const int nk = p.K / (F8 ? 2 * BK : SPLIT ? BK / 2 : BK);   // even, >= 2 (checked by the launcher)
+    constexpr int ESZ = F8 ? 1 : SPLIT ? 4 : 2;        // bytes per operand element: a K-tile is always 128 bytes per row
     // operands are addressed through buffer descriptors (SGPRs) + a 32-bit per-lane offset + a scalar K-tile offset:
     // no 64-bit address arithmetic per LDS-DMA, fewer VGPRs (what lets a LayerNorm wave of the other lane share a SIMD)
     const __amdgpu_buffer_rsrc_t Arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(F8 ? reinterpret_cast<const void*>(p.A8) : reinterpret_cast<const void*>(p.A)), 0, 0x7fffffff, 0x00020000);
+        const_cast<void*>(F8 || SPLIT ? reinterpret_cast<const void*>(p.A8) : reinterpret_cast<const void*>(p.A)), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t Wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(F8 ? reinterpret_cast<const void*>(p.W8) : reinterpret_cast<const void*>(p.W)), 0, 0x7fffffff, 0x00020000);
+        const_cast<void*>(F8 || SPLIT ? reinterpret_cast<const void*>(p.W8) : reinterpret_cast<const void*>(p.W)), 0, 0x7fffffff, 0x00020000);
     char* const sc_lds = smem + pp_lds_main<TA, TB>(); // F8: [buf][A rows 256 x 4 B | B rows 256 x 4 B]
 
     // ---- LDS-DMA source offsets: two 8-row pieces per wave and sub-tile --------------------------
@@ -254,6 +256,17 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
             for (int i = 0; i < T; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[I0 + i][hb * 2 + j]));
+        } else if constexpr (SPLIT) {
+            // h[0] = the hi halves of the K-tile's 32 k-values, h[1] = the lo halves; per accumulator the three products in
+            // the order of vit_f32.hip's split kernels (w_lo a_hi, w_hi a_lo, w_hi a_hi): bit-identical results
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[I0 + i][hb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            bf[j].h[term == 0 ? 1 : 0], a[i].h[term == 1 ? 1 : 0], acc[I0 + i][hb * 2 + j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -376,6 +389,12 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
         asm volatile("" : "+v"(lane));
         if (has_next) set_tile(next);                     // the staging offsets now describe the NEXT tile
         // every wave is past the loop: buffer 0 is free, and the scratch below lies over buffer 1
+        if constexpr (SPLIT) {
+            // precision 4: the fp32-schedule epilogues of vit32_epilogue.h
+            vit32_epilogue_tile<EPI, TM>(sp, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
+                if (has_next) { stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
+            });
+        } else
         gemm_epilogue_tile<EPI, TM>(p, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
             if (has_next) { load_lnp(); stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
         }, rope_lds, EPI == EPI_RESID_LN ? reinterpret_cast<f32x2*>(ln_lds) + (wr * WROWS) * 4 + wc
@@ -447,6 +466,24 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmParams p, PPGr
     }
 }
 
+// precision 4: the same loop on split operands (hi | lo halves of 32 k-values per 128-byte K-tile row), epilogues of the
+// fp32 schedule.  p carries the loop's view of the problem (byte pointers in A8 / W8, lda and K in floats), sp the epilogue's.
+template <int EPI, int TA, int TB, int TAIL>
+__global__ __launch_bounds__(512, 2) void gemm_split_pp_kernel(GemmParams p, PPGrid g, Gemm32VitParams sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = p.N / BN;
+    const int G = gridDim.x;
+    int first = blockIdx.x;
+    if (first < g.main_blocks) {
+        pp_tiles<EPI, TA, TB, false, true>(p, smem, first, g.main_blocks, G, 0, tiles_n, nullptr, nullptr, sp);
+        first += ((g.main_blocks - 1 - first) / G + 1) * G;
+    }
+    if (TAIL && first < g.n_tiles) {
+        __syncthreads();
+        pp_tiles<EPI, 2, 2, false, true>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n, nullptr, nullptr, sp);
+    }
+}
+
 int pp_cus() {
     static const int cus = [] {
         int dev = 0, n = 256;
@@ -497,7 +534,11 @@ int launch_8ph(const GemmParams& p, int main_panels, hipStream_t stream) {
 // Makespan of a launch on `slots` CUs, in units of one 256x256 tile: tiles are handed out in block
 // order to whichever CU frees up first.  Relative tile costs measured with scripts/gemm_stamps.py
 // (the smaller tiles are bound by the ~30 B/cycle/CU L2->LDS rate, not by the MFMA pipe).
-double pp_tile_cost(int bm) { return bm == 256 ? 1.0 : bm == 192 ? 0.86 : bm == 160 ? 0.83 : 0.66; }
+// The split form's loop is three times as long per staged byte and MFMA-bound at every tile height: cost ~ rows.
+double pp_tile_cost(int bm, bool split = false) {
+    if (split) return 0.05 + 0.95 * bm / 256.0;
+    return bm == 256 ? 1.0 : bm == 192 ? 0.86 : bm == 160 ? 0.83 : 0.66;
+}
 
 double pp_makespan(int n_main, double c_main, int n_tail, double c_tail, int slots) {
     std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
@@ -519,32 +560,33 @@ double pp_makespan(int n_main, double c_main, int n_tail, double c_tail, int slo
 struct PPPlan { int bm; int main_panels; };
 
 // plan for an (M, N) problem on this device; computed once per shape
-PPPlan pp_plan(int M, int N) {
+PPPlan pp_plan(int M, int N, bool split = false) {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, PPPlan> cache;
+    static std::map<std::pair<int, int>, PPPlan> cache;            // key: (M, +-N)
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find({M, N});
+    const std::pair<int, int> key{M, split ? -N : N};
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const int tiles_n = N / BN;
     PPPlan best{256, 0};
     double best_t = 1e30;
     for (int bm : {256, 192, 160}) {
         const int n = ((M + bm - 1) / bm) * tiles_n;
-        const double t = pp_makespan(n, pp_tile_cost(bm), 0, 0.0, cus);
+        const double t = pp_makespan(n, pp_tile_cost(bm, split), 0, 0.0, cus);
         if (t < best_t - 1e-9) { best = {bm, 0}; best_t = t; }
     }
     static const bool no_tail = [] { const char* e = getenv("CBAS_PP_NO_TAIL"); return e && e[0] == '1'; }();   // experiments
     for (int mp = 1; mp * 256 < M && !no_tail; ++mp) {
         const int n_main = mp * tiles_n, n_tail = ((M - mp * 256 + 127) / 128) * tiles_n;
-        const double t = pp_makespan(n_main, 1.0, n_tail, pp_tile_cost(128), cus);
+        const double t = pp_makespan(n_main, 1.0, n_tail, pp_tile_cost(128, split), cus);
         if (t < best_t - 0.02) { best = {256, mp}; best_t = t; }      // prefer a uniform grid on near-ties
     }
-    cache[{M, N}] = best;
+    cache[key] = best;
     return best;
 }
 
@@ -564,7 +606,79 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
     return launch_8ph<EPI, 4, 4, 0, F8>(p, 0, stream);
 }
 
+template <int EPI, int TA, int TB, int TAIL>
+int launch_split_pp(const GemmParams& p, const Gemm32VitParams& sp, int main_panels, hipStream_t stream) {
+    constexpr int BM = 32 * (TA + TB);
+    constexpr int lds = pp_lds_kernel<TA, TB, TAIL, false>();
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_pp_kernel<EPI, TA, TB, TAIL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const int tiles_n = p.N / BN;
+    PPGrid g;
+    if (TAIL) {
+        g.main_blocks = main_panels * tiles_n;
+        g.tail_row0 = main_panels * BM;
+        if (g.tail_row0 >= p.M) return -1;
+        g.n_tiles = g.main_blocks + ((p.M - g.tail_row0 + 127) / 128) * tiles_n;
+    } else {
+        g.n_tiles = ((p.M + BM - 1) / BM) * tiles_n;
+        g.main_blocks = g.n_tiles;
+        g.tail_row0 = p.M;
+    }
+    const int slots = pp_cus() & ~7;
+    const int grid = g.n_tiles > slots ? slots : g.n_tiles;
+    hipLaunchKernelGGL((gemm_split_pp_kernel<EPI, TA, TB, TAIL>), dim3(grid), dim3(512), lds, stream, p, g, sp);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int g_split_tile = 0;                          // bring-up (gemm_split_pp_debug): forced tile height, stamps buffer
+unsigned long long* g_split_stamps = nullptr;
+
+template <int EPI>
+int launch_split_pp_epi(const GemmParams& p, const Gemm32VitParams& sp, hipStream_t stream) {
+    static const int tile_env0 = [] { const char* e = getenv("CBAS_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // experiments
+    const int tile_env = g_split_tile ? g_split_tile : tile_env0;
+    if (tile_env == 256) return launch_split_pp<EPI, 4, 4, 0>(p, sp, 0, stream);
+    if (tile_env == 192) return launch_split_pp<EPI, 3, 3, 0>(p, sp, 0, stream);
+    if (tile_env == 160) return launch_split_pp<EPI, 3, 2, 0>(p, sp, 0, stream);
+    if (tile_env == 128) return launch_split_pp<EPI, 2, 2, 0>(p, sp, 0, stream);
+    const PPPlan plan = pp_plan(p.M, p.N, true);
+    if (plan.main_panels) return launch_split_pp<EPI, 4, 4, 1>(p, sp, plan.main_panels, stream);
+    if (plan.bm == 192) return launch_split_pp<EPI, 3, 3, 0>(p, sp, 0, stream);
+    if (plan.bm == 160) return launch_split_pp<EPI, 3, 2, 0>(p, sp, 0, stream);
+    return launch_split_pp<EPI, 4, 4, 0>(p, sp, 0, stream);
+}
+
 }  // namespace
+
+void gemm_split_pp_debug(int tile, unsigned long long* stamps) { g_split_tile = tile; g_split_stamps = stamps; }
+
+// precision 4, large M: -1 when the shape is not this kernel's (the caller keeps its 128 x 128 kernels for those)
+int launch_gemm_split_pp(GemmEpilogue epi, const Gemm32VitParams& sp, hipStream_t stream) {
+    if (!sp.split || sp.N % 256 || sp.K % 64 || sp.K < 64 || sp.M < 1) return -1;
+    if ((long long)sp.M * sp.lda * 4 >= (1ll << 31) || (long long)sp.N * sp.K * 4 >= (1ll << 31)) return -1;
+    GemmParams p{};
+    p.A8 = reinterpret_cast<const uint8_t*>(sp.A);
+    p.W8 = reinterpret_cast<const uint8_t*>(sp.W);
+    p.lda = (int)sp.lda;
+    p.M = sp.M;
+    p.M_pad = sp.M;
+    p.N = sp.N;
+    p.K = sp.K;
+    p.stamps = g_split_stamps;
+    switch (epi) {
+        case EPI_PATCH: return launch_split_pp_epi<EPI_PATCH>(p, sp, stream);
+        case EPI_QKV:   return launch_split_pp_epi<EPI_QKV>(p, sp, stream);
+        case EPI_RESID: return launch_split_pp_epi<EPI_RESID>(p, sp, stream);
+        case EPI_GELU:  return launch_split_pp_epi<EPI_GELU>(p, sp, stream);
+        default: return -1;
+    }
+}
 
 int launch_gemm_8ph(GemmEpilogue epi, const GemmParams& p_in, int tile, hipStream_t stream) {
     GemmParams p = p_in;

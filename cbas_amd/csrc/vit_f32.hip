@@ -23,139 +23,11 @@
 #include <stdlib.h>
 #include "kernels.h"
 #include "gemm_f32_tile.h"
+#include "vit32_epilogue.h"
 
 namespace {
 
 using namespace f32tile;
-
-// ---------------------------------------------------------------------------------------------------------------------
-// precision 4: the same fp32 schedule with every GEMM's products on the fp16 matrix pipe.  An fp32 value x (times a power
-// of two) is kept as hi + lo, hi = fp16(x), lo = fp16(x - hi): 22 significant bits;
-//      a w  ~  a_hi w_hi + a_hi w_lo + a_lo w_hi        on v_mfma_f32_16x16x32_f16
-// (fp16 products are exact in fp32; the dropped a_lo w_lo term and the two representation residues are ~2^-22 of the
-// product each; the MFMA sums a 32-product block before it rounds into the fp32 accumulator, which makes the result
-// CLOSER to the reference's blocked CPU GEMM than the k-ordered fmaf chain of precision 3: measured).
-//
-// Split operands live in memory in the GEMM's LDS image order, at the byte size of the fp32 array they replace: the 32
-// k-values of a K-tile of a row are 128 bytes = [hi: 32 x fp16 | lo: 32 x fp16], and inside each half the value of
-// k = 16 h + 4 g + e (h = 0, 1; g, e = 0..3) sits at position 8 g + 4 h + e - so the 16-byte chunk g of the hi half (chunk
-// 4 + g for lo) is exactly the 8 k-values lane group g feeds one MFMA, and the staging / swizzle / fragment reads are the
-// fp32 kernel's own.  Producers (LayerNorm, attention, the GELU epilogue, ingest, the weight packer) write this format,
-// each value split ONCE; the GEMM loop is fragment reads + 48 MFMAs per K-tile per wave, no conversions.
-// ---------------------------------------------------------------------------------------------------------------------
-typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
-// four consecutive columns c .. c+3 (c % 4 == 0) of a row that starts at `row` (float-sized slots): hi and lo halves
-__device__ __forceinline__ void store_split4(float* row, int c, f32x4 v, float scale) {
-    const int kk = c & 31;
-    char* tile = reinterpret_cast<char*>(row + (c - kk));                       // the K-tile's 128 bytes
-    const int pos = (((kk & 15) >> 2) << 3) + ((kk >> 4) << 2);                 // 8 g + 4 h
-    f16x4v hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e] * scale;
-        const f16 h = (f16)x;
-        hi[e] = h;
-        lo[e] = (f16)(x - (float)h);
-    }
-    *reinterpret_cast<f16x4v*>(tile + pos * 2) = hi;
-    *reinterpret_cast<f16x4v*>(tile + 64 + pos * 2) = lo;
-}
-
-// Attention operands of precision 4: the 64 values of one head of q, k or v (256 bytes as fp32) become
-// [hi: 64 x fp16 | lo: 64 x fp16] in natural d order - 128-byte rows, the fp16 attention kernels' K / V row geometry.
-// Scales (powers of two, undone exactly in the kernel): q x 16 on top of its 1/8, k x 4, v x 4; probabilities x 1024.
-constexpr float ATT_QS = 16.f, ATT_KS = 4.f, ATT_VS = 4.f, ATT_PS = 1024.f;
-__device__ __forceinline__ void store_head_split4(float* head, int d, f32x4 v, float scale) {
-    f16x4v hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e] * scale;
-        const f16 h = (f16)x;
-        hi[e] = h;
-        lo[e] = (f16)(x - (float)h);
-    }
-    char* b = reinterpret_cast<char*>(head);
-    *reinterpret_cast<f16x4v*>(b + d * 2) = hi;
-    *reinterpret_cast<f16x4v*>(b + 128 + d * 2) = lo;
-}
-
-// a*c + b*s with every product and the sum rounded on its own, as the reference's `(q * cos) + (rotate_half(q) * sin)`
-__device__ __forceinline__ f32x4 rope_rot32(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
-#pragma clang fp contract(off)
-    const f32x4 t0 = a * c;
-    const f32x4 t1 = b * s;
-    return t0 + t1;
-}
-
-template <int EPI>
-__device__ __forceinline__ void vit32_epilogue_row(const Gemm32VitParams& p, int m, int head_col0, int lane,
-                                                   const f32x4 (&acc)[4]) {
-#pragma clang fp contract(off)
-    const int ncol = head_col0 + (lane >> 4) * 4;     // + j*16
-    if (EPI == EPI_PATCH) {
-        const int b = m / p.patches_per_frame;
-        const int pp = m - b * p.patches_per_frame;
-        const int64_t orow = (int64_t)b * p.tokens_per_frame + p.n_prefix + pp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol + j * 16;
-            f32x4 v = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.pos) v = v + *reinterpret_cast<const f32x4*>(p.pos + (size_t)pp * p.N + n);
-            *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + n) = v;
-        }
-    } else if (EPI == EPI_QKV) {
-        const int sec = head_col0 / p.D + p.sec0;      // 0 q, 1 k, 2 v: uniform over the 64-column group
-        const int t = m % p.tokens_per_frame;
-        const bool rope = p.rope_cos && (sec < 2) && (t >= p.n_prefix);
-        f32x4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + ncol + j * 16);
-        if (rope) {
-            const size_t ro = (size_t)(t - p.n_prefix) * 64 + (lane >> 4) * 4;
-            f32x4 o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
-                // rotate_half(x)[d] = -x[d+32] (d < 32), x[d-32] (d >= 32)
-                o[j] = (j < 2) ? rope_rot32(v[j], c, -v[j + 2], s) : rope_rot32(v[j], c, v[j - 2], s);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = o[j];
-        }
-        const float qs = (sec == 0) ? 0.125f : 1.0f;   // head_dim^-0.5, an exact power of two: commutes with every rounding
-        if (p.split) {                                  // precision 4: the attention kernel's split operands
-            const float sc = sec == 0 ? 0.125f * ATT_QS : (sec == 1 ? ATT_KS : ATT_VS);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                store_head_split4(p.out + (int64_t)m * p.ldo + head_col0, j * 16 + (lane >> 4) * 4, v[j], sc);
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + ncol + j * 16) = v[j] * qs;
-    } else if (EPI == EPI_RESID) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol + j * 16;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-            const f32x4 lv = *reinterpret_cast<const f32x4*>(p.lambda + n);
-            float* xp = p.out + (int64_t)m * p.ldo + n;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp);
-            const f32x4 hsc = (acc[j] + bv) * lv;       // layer_scale(linear(.)), rounded as its own op
-            *reinterpret_cast<f32x4*>(xp) = hsc + xv;   // + residual
-        }
-    } else {  // EPI_GELU
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol + j * 16;
-            const f32x4 w = acc[j] + *reinterpret_cast<const f32x4*>(p.bias + n);
-            const f32x4 gv = f32x4{gelu_erf(w[0]), gelu_erf(w[1]), gelu_erf(w[2]), gelu_erf(w[3])};
-            if (p.split) store_split4(p.out + (int64_t)m * p.ldo, n, gv, p.out_scale);      // the down projection's A operand
-            else *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = gv;
-        }
-    }
-}
 
 template <int EPI, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_vit_kernel(Gemm32VitParams p) {
@@ -387,7 +259,15 @@ int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
 template <int EPI>
 int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
     if (!p.split) return launch_vit32s<EPI, false>(p, stream);
-    return p.M > 256 ? launch_split8<EPI>(p, stream) : launch_vit32s<EPI, true>(p, stream);
+    if (p.M <= 256) return launch_vit32s<EPI, true>(p, stream);
+    // large M: the ping-pong kernel's split form (gemm_f16_8ph.hip) where the shape is one of its; all three kernels form
+    // the same products in the same order, so the choice does not show in the results
+    static const bool pp = [] { const char* e = getenv("CBAS_SPLIT_PP"); return !e || e[0] != '0'; }();
+    if (pp) {
+        const int rc = launch_gemm_split_pp((GemmEpilogue)EPI, p, stream);
+        if (rc != -1) return rc;
+    }
+    return launch_split8<EPI>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
