@@ -416,7 +416,13 @@ int run_blocks_f32(cbas_enc* h, int n, int height, int width, float* cls_f32, f1
     const bool prune = h->prune_last && stop_layer < 0 && (cls_f32 || cls_f16);
     auto qkv_params = [&](const LayerW& w, Gemm32VitParams& q) {
         q.K = D; q.D = D; q.tokens_per_frame = T; q.n_prefix = h->NP;
-        if (h->cfg.use_rope) { q.rope_cos = h->rope_cos; q.rope_sin = h->rope_sin; }
+        if (h->cfg.use_rope) {
+            q.rope_cos = h->rope_cos; q.rope_sin = h->rope_sin;
+            if (h->rope_in_lds) {
+                q.rope_fac = h->rope_fac; q.rope_nh = h->rope_nh; q.rope_nw = h->rope_nw;
+                q.rope_magic = (unsigned)((1ull << 32) / (unsigned)h->rope_nw) + 1u;
+            }
+        }
     };
     for (int l = 0; l < h->L; ++l) {
         const LayerW& w = h->layers[l];
@@ -1375,6 +1381,7 @@ extern "C" int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int til
     Gemm32VitParams p{};
     p.A = A; p.lda = K; p.W = Wt; p.M = M; p.N = N; p.K = K; p.bias = bias; p.lambda = bias; p.out = out; p.ldo = N;
     p.tokens_per_frame = 201; p.n_prefix = 5; p.patches_per_frame = 196; p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3;
+    p.rope_fac = rope; p.rope_nh = 14; p.rope_nw = 14; p.rope_magic = (unsigned)((1ull << 32) / 14u) + 1u;   // zeros: timing only
     p.split = 1; p.a_scale = 1.f; p.w_scale = 1.f; p.out_scale = 1.f;
     const GemmEpilogue e = (GemmEpilogue)epi;
     auto run = [&]() { return tile < 0 ? launch_gemm_f32_vit(e, p, 0) : launch_gemm_split_pp(e, p, 0); };

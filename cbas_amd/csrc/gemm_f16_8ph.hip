@@ -393,7 +393,7 @@ __device__ __forceinline__ void pp_tiles(const GemmParams& p, char* smem, int fi
             // precision 4: the fp32-schedule epilogues of vit32_epilogue.h
             vit32_epilogue_tile<EPI, TM>(sp, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
                 if (has_next) { stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
-            });
+            }, rope_lds);
         } else
         gemm_epilogue_tile<EPI, TM>(p, erow, ecol, lane, acc, smem + BUF_BYTES + wave * 8192, [&] {
             if (has_next) { load_lnp(); stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2); stage(0, 0, 3); }
@@ -473,14 +473,24 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pp_kernel(GemmParams p, PPG
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N / BN;
     const int G = gridDim.x;
+    // q|k|v: the RoPE angles by axis live in LDS behind the staging buffers for the life of the workgroup
+    const float* rope_lds = nullptr;
+    if (EPI == EPI_QKV && sp.rope_fac) {
+        float* dst = reinterpret_cast<float*>(smem + pp_lds_kernel<TA, TB, TAIL, false>());
+        const int n4 = (sp.rope_nh + sp.rope_nw) * 8;          // 16-byte pieces
+        for (int i = threadIdx.x; i < n4; i += 512)
+            reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(sp.rope_fac)[i];
+        __syncthreads();
+        rope_lds = dst;
+    }
     int first = blockIdx.x;
     if (first < g.main_blocks) {
-        pp_tiles<EPI, TA, TB, false, true>(p, smem, first, g.main_blocks, G, 0, tiles_n, nullptr, nullptr, sp);
+        pp_tiles<EPI, TA, TB, false, true>(p, smem, first, g.main_blocks, G, 0, tiles_n, rope_lds, nullptr, sp);
         first += ((g.main_blocks - 1 - first) / G + 1) * G;
     }
     if (TAIL && first < g.n_tiles) {
         __syncthreads();
-        pp_tiles<EPI, 2, 2, false, true>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n, nullptr, nullptr, sp);
+        pp_tiles<EPI, 2, 2, false, true>(p, smem, first - g.main_blocks, g.n_tiles - g.main_blocks, G, g.tail_row0, tiles_n, rope_lds, nullptr, sp);
     }
 }
 
@@ -609,7 +619,7 @@ int launch_8ph_epi(const GemmParams& p, int tile, hipStream_t stream) {
 template <int EPI, int TA, int TB, int TAIL>
 int launch_split_pp(const GemmParams& p, const Gemm32VitParams& sp, int main_panels, hipStream_t stream) {
     constexpr int BM = 32 * (TA + TB);
-    constexpr int lds = pp_lds_kernel<TA, TB, TAIL, false>();
+    constexpr int lds = pp_lds_kernel<TA, TB, TAIL, false>() + (EPI == EPI_QKV ? ROPE_LDS_ROWS * 128 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -632,7 +642,8 @@ int launch_split_pp(const GemmParams& p, const Gemm32VitParams& sp, int main_pan
     }
     const int slots = pp_cus() & ~7;
     const int grid = g.n_tiles > slots ? slots : g.n_tiles;
-    hipLaunchKernelGGL((gemm_split_pp_kernel<EPI, TA, TB, TAIL>), dim3(grid), dim3(512), lds, stream, p, g, sp);
+    const int lds_launch = pp_lds_kernel<TA, TB, TAIL, false>() + (EPI == EPI_QKV && sp.rope_fac ? (sp.rope_nh + sp.rope_nw) * 128 : 0);
+    hipLaunchKernelGGL((gemm_split_pp_kernel<EPI, TA, TB, TAIL>), dim3(grid), dim3(512), lds_launch, stream, p, g, sp);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -659,7 +670,10 @@ int launch_split_pp_epi(const GemmParams& p, const Gemm32VitParams& sp, hipStrea
 void gemm_split_pp_debug(int tile, unsigned long long* stamps) { g_split_tile = tile; g_split_stamps = stamps; }
 
 // precision 4, large M: -1 when the shape is not this kernel's (the caller keeps its 128 x 128 kernels for those)
-int launch_gemm_split_pp(GemmEpilogue epi, const Gemm32VitParams& sp, hipStream_t stream) {
+int launch_gemm_split_pp(GemmEpilogue epi, const Gemm32VitParams& sp_in, hipStream_t stream) {
+    Gemm32VitParams sp = sp_in;
+    // the LDS copy of the RoPE angles, or the global [P][64] tables
+    if (sp.rope_fac && (!sp.rope_cos || sp.rope_nw <= 1 || sp.rope_nh + sp.rope_nw > ROPE_LDS_ROWS)) sp.rope_fac = nullptr;
     if (!sp.split || sp.N % 256 || sp.K % 64 || sp.K < 64 || sp.M < 1) return -1;
     if ((long long)sp.M * sp.lda * 4 >= (1ll << 31) || (long long)sp.N * sp.K * 4 >= (1ll << 31)) return -1;
     GemmParams p{};

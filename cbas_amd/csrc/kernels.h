@@ -158,6 +158,8 @@ struct Gemm32VitParams {
     // EPI_QKV
     const float* rope_cos;         // [P][64], or nullptr: no RoPE
     const float* rope_sin;
+    // the same numbers by axis (GemmParams::rope_fac): the ping-pong kernel's split form keeps them in LDS (or nullptr)
+    const float* rope_fac; int rope_nh, rope_nw; unsigned rope_magic;
     int D;                         // hidden size (q | k | v sections of width D)
     int sec0;                      // section of output column 0
     // precision 4: the same fp32 operands, products on the fp16 matrix pipe as a three-term split (vit_f32.hip).

@@ -192,7 +192,7 @@ __device__ __forceinline__ void vit32_epilogue_row(const Gemm32VitParams& p, int
 // ---------------------------------------------------------------------------------------------------------------------
 template <int EPI, int TM, typename Pre>
 __device__ __forceinline__ void vit32_epilogue_tile(const Gemm32VitParams& p, int row_base, int head_col0, int lane,
-                                                    f32x4 (&acc)[TM][4], char* scratch, Pre pre) {
+                                                    f32x4 (&acc)[TM][4], char* scratch, Pre pre, const float* rope_lds = nullptr) {
 #pragma clang fp contract(off)
     const int li = lane & 15, g = lane >> 4;
     const float unscale = 1.0f / (p.a_scale * p.w_scale);     // powers of two: exact
@@ -253,6 +253,8 @@ __device__ __forceinline__ void vit32_epilogue_tile(const Gemm32VitParams& p, in
     const int sec = EPI == EPI_QKV ? head_col0 / p.D + p.sec0 : 2;      // 0 q, 1 k, 2 v: uniform over the 64-column group
     const bool rope_sec = EPI == EPI_QKV && p.rope_cos && sec < 2;
     const float qsc = sec == 0 ? 0.125f * ATT_QS : (sec == 1 ? ATT_KS : ATT_VS);
+    // token index of this lane's row in the slab at hand: one division per tile, then + 16 with a wrap
+    int t_row = rope_sec ? (row_base + li) % p.tokens_per_frame : 0;
     pre();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -261,19 +263,37 @@ __device__ __forceinline__ void vit32_epilogue_tile(const Gemm32VitParams& p, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[i][j] * unscale + bv[j];
         if (EPI == EPI_QKV) {
-            const int m = row_base + i * 16 + li;
-            const int t = m % p.tokens_per_frame;
-            if (rope_sec && t >= p.n_prefix) {
-                const size_t ro = (size_t)(t - p.n_prefix) * 64 + g * 4;
+            if (rope_sec) {
+                const int pr = t_row - p.n_prefix;
+                const bool rot = pr >= 0;                              // prefix rows (cls, registers) are not rotated
+                const int pp = pr > 0 ? pr : 0;
+                f32x4 c[2], s[2];                                      // columns g*4.. of the 16-column groups 0 and 1; 2, 3 repeat them ([tf]:190)
+                if (rope_lds) {
+                    // the angles by axis, in LDS: group 0 depends on the patch row only, group 1 on the patch column ([tf]:96-121)
+                    const int iy = (int)__umulhi((unsigned)pp, p.rope_magic), ix = pp - iy * p.rope_nw;
+                    const float* ry = rope_lds + iy * 32 + g * 4;
+                    const float* rx = rope_lds + (p.rope_nh + ix) * 32 + g * 4;
+                    c[0] = *reinterpret_cast<const f32x4*>(ry);
+                    s[0] = *reinterpret_cast<const f32x4*>(ry + 16);
+                    c[1] = *reinterpret_cast<const f32x4*>(rx);
+                    s[1] = *reinterpret_cast<const f32x4*>(rx + 16);
+                } else {
+                    const size_t ro = (size_t)pp * 64 + g * 4;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        c[j] = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
+                        s[j] = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
+                    }
+                }
                 f32x4 o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + ro + j * 16);
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + ro + j * 16);
-                    o[j] = (j < 2) ? rope_rot32(v[j], c, -v[j + 2], s) : rope_rot32(v[j], c, v[j - 2], s);
-                }
+                for (int j = 0; j < 4; ++j)
+                    o[j] = (j < 2) ? rope_rot32(v[j], c[j], -v[j + 2], s[j]) : rope_rot32(v[j], c[j - 2], v[j - 2], s[j - 2]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = o[j];
+                for (int j = 0; j < 4; ++j) v[j] = rot ? o[j] : v[j];
+                t_row += 16;
+                if (p.tokens_per_frame >= 16) t_row -= t_row >= p.tokens_per_frame ? p.tokens_per_frame : 0;
+                else t_row %= p.tokens_per_frame;
             }
             // [hi: d = 0..63 | lo]: the 8-byte piece of (j, g) is half g & 1 of chunk 2 j + (g >> 1) (+ 8 for lo)
 #pragma unroll

@@ -21,6 +21,7 @@
 // The matrix pipe runs at 1/16 of the fp16 rate here (157 TFLOP/s peak), so the GEMM is MFMA-bound by a wide margin
 // and the geometry is the simple one of gemm_f32.hip: 128x128 tiles, 4 waves, two LDS buffers, LDS-DMA staging.
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 #include "gemm_f32_tile.h"
 #include "vit32_epilogue.h"
@@ -240,6 +241,97 @@ int launch_split8(const Gemm32VitParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// precision 4, M <= 256: the CLS rows of the pruned last layer (q, o_proj, up, down on n frames; [tf]:540-541,
+// backend/cbas.py:677).  There are only N / 64 x ceil(M / 64) tiles of work and K is up to 3 072: on the 2-buffer kernel
+// above every K-tile pays one global -> LDS round trip (K = 3 072: 96 of them, 63 us).  Here, as in gemm_f16_skinny.hip, a
+// workgroup is 4 waves x (16 rows x 64 columns) over an 8-slot LDS ring filled by LDS-DMA with 6 K-tiles in flight under
+// a counted vmcnt and ONE raw barrier per K-tile.  Same products in the same order per output element as the other
+// split kernels: bit-identical rows, so a frame's CLS row does not depend on its batch.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SS_NS = 8;                                // ring slots
+constexpr int SS_STAGE = 2 * 64 * 128;                  // A 64 rows + W 64 rows, 128 bytes (one K-tile: 32 k, hi | lo) each
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_split_skinny_kernel(Gemm32VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
+    const int nk = p.K / BKF;
+
+    const int lrow = lane >> 3;
+    const float* a_src[2];
+    const float* b_src[2];
+    int lds_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r = (wave + 4 * s) * 8 + lrow;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t ar = row0 + r;
+        ar = ar < p.M ? ar : p.M - 1;                   // rows past the end are never stored
+        a_src[s] = p.A + ar * p.lda + chunk * 4;
+        b_src[s] = p.W + (int64_t)(col0 + r) * p.K + chunk * 4;
+        lds_off[s] = (wave + 4 * s) * 1024;
+    }
+    auto stage = [&](int kt) {
+        char* base = smem + (kt % SS_NS) * SS_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[s] + kt * BKF), LDS_PTR(base + lds_off[s]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[s] + kt * BKF), LDS_PTR(base + 8192 + lds_off[s]), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 15, fchunk = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < SS_NS - 1 && kt < nk; ++kt) stage(kt);           // 7 K-tiles in flight
+    for (int kt = 0; kt < nk; ++kt) {
+        // K-tile kt has landed once at most the 6 younger stages (4 DMAs each per wave) are outstanding
+        if (kt + SS_NS - 2 < nk) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // ... for every wave's pieces; and every wave
+        if (kt + SS_NS - 1 < nk) stage(kt + SS_NS - 1);                    // is done with slot (kt-1) % NS, refilled here
+        const char* At = smem + (kt % SS_NS) * SS_STAGE;
+        const char* Wt = At + 8192;
+        const f16x8 ah = __builtin_bit_cast(f16x8, read_frag32(At, wave * 16 + frow, fchunk));
+        const f16x8 al = __builtin_bit_cast(f16x8, read_frag32(At, wave * 16 + frow, 4 + fchunk));
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = __builtin_bit_cast(f16x8, read_frag32(Wt, j * 16 + frow, fchunk));
+            bl[j] = __builtin_bit_cast(f16x8, read_frag32(Wt, j * 16 + frow, 4 + fchunk));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc[j], 0, 0, 0);
+    }
+    const float unscale = 1.0f / (p.a_scale * p.w_scale);     // powers of two: exact
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= unscale;
+    const int m = row0 + wave * 16 + (lane & 15);
+    if (m < p.M) vit32_epilogue_row<EPI>(p, m, col0, lane, acc);
+}
+
+template <int EPI>
+int launch_split_skinny(const Gemm32VitParams& p, hipStream_t stream) {
+    constexpr int lds = SS_NS * SS_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_skinny_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_split_skinny_kernel<EPI>), dim3((unsigned)(p.N / 64), (unsigned)((p.M + 63) / 64)), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int EPI, bool SPLIT>
 int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
     constexpr int lds = 4 * TILE_BYTES;
@@ -259,7 +351,10 @@ int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
 template <int EPI>
 int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
     if (!p.split) return launch_vit32s<EPI, false>(p, stream);
-    if (p.M <= 256) return launch_vit32s<EPI, true>(p, stream);
+    if (p.M <= 256) {
+        static const bool skinny = [] { const char* e = getenv("CBAS_SPLIT_SKINNY"); return !e || e[0] != '0'; }();
+        return skinny && EPI != EPI_PATCH ? launch_split_skinny<EPI>(p, stream) : launch_vit32s<EPI, true>(p, stream);
+    }
     // large M: the ping-pong kernel's split form (gemm_f16_8ph.hip) where the shape is one of its; all three kernels form
     // the same products in the same order, so the choice does not show in the results
     static const bool pp = [] { const char* e = getenv("CBAS_SPLIT_PP"); return !e || e[0] != '0'; }();
@@ -550,6 +645,9 @@ __device__ __forceinline__ float exp_neg(float x) {
     return fmaf(e, r * 0.693147181f, e);
 }
 
+// Measured and removed (r4): a resident form for T <= 256 - one workgroup per (frame, head), one wave per query tile, every
+// key block staged up front (4 x 32 KiB), one barrier, then free-running waves: 71-73 us per layer against this ring's
+// 64-68 (ViT-B/16 batch 64, bit-identical rows): the kernel is not bound by its barriers or by staging K / V twice.
 __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                  float* __restrict__ out, int T, int D, int n_heads, int qblocks,
                                                                  float out_scale) {
@@ -598,84 +696,91 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr float S_UNSCALE = 1.0f / (ATT_QS * ATT_KS);
 
+    auto block = [&](int kb, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const char* Kh = smem + (kb & 1) * 4 * SIMG;
+        const char* Kl = Kh + SIMG;
+        const char* Vh = Kl + SIMG;
+        const char* Vl = Vh + SIMG;
+        const int left = T - kb * AKB;
+        const int nkt = FULL ? 4 : (left + 15) >> 4;              // key tiles with at least one real key (wave-uniform)
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (!FULL && kt >= nkt) { s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
+            }
+            s[kt] = acc * S_UNSCALE;
+        }
+        if (!FULL) {                                              // only a partial block can hold keys past T
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
+        bm = xor16_max(bm);
+        bm = xor32_max(bm);
+        const float mnew = fmaxf(mrun, bm);
+        const float alpha = exp_neg(mrun - mnew);
+        float psum = 0.f;
+        f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp_neg(s[2 * grp + u][r] - mnew);
+                    psum += pv;
+                    const float x = pv * ATT_PS;
+                    const f16 h = (f16)x;
+                    ph[grp][4 * u + r] = h;
+                    pl[grp][4 * u + r] = (f16)(x - (float)h);
+                }
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (!FULL && 2 * s2 >= nkt) continue;                 // both tiles of the group are padding
+            const int krow = 32 * s2 + 4 * g + (li >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = 16 * dt + 4 * (li & 3);
+                union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
+                uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
+                uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
+                ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
+                ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
+            }
+        }
+    };
     for (int kb = 0; kb < nkb; ++kb) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
         __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
         if (kb + 1 < nkb) stage((kb + 1) & 1, kb + 1);
         if (active) {
-            const char* Kh = smem + (kb & 1) * 4 * SIMG;
-            const char* Kl = Kh + SIMG;
-            const char* Vh = Kl + SIMG;
-            const char* Vl = Vh + SIMG;
-            const int left = T - kb * AKB;
-            const int nkt = left >= AKB ? 4 : (left + 15) >> 4;       // key tiles with at least one real key (wave-uniform)
-            f32x4 s[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt >= nkt) { s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
-                    const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
-                }
-                s[kt] = acc * S_UNSCALE;
-            }
-            if (kb == nkb - 1) {                                      // only the last block can hold keys past T (scalar branch)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
-            }
-            float bm = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
-            bm = xor16_max(bm);
-            bm = xor32_max(bm);
-            const float mnew = fmaxf(mrun, bm);
-            const float alpha = exp_neg(mrun - mnew);
-            float psum = 0.f;
-            f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
-#pragma unroll
-            for (int grp = 0; grp < 2; ++grp)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = exp_neg(s[2 * grp + u][r] - mnew);
-                        psum += pv;
-                        const float x = pv * ATT_PS;
-                        const f16 h = (f16)x;
-                        ph[grp][4 * u + r] = h;
-                        pl[grp][4 * u + r] = (f16)(x - (float)h);
-                    }
-            lrun = lrun * alpha + psum;
-            mrun = mnew;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (2 * s2 >= nkt) continue;                          // both tiles of the group are padding
-                const int krow = 32 * s2 + 4 * g + (li >> 2);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int col = 16 * dt + 4 * (li & 3);
-                    union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
-                    uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
-                    uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
-                    ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
-                    ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
-                }
-            }
+            // a full block (64 real keys: every block but the last) runs without the per-tile tests, so that its four key
+            // tiles are four independent MFMA chains in one basic block; same operations per query either way
+            if (T - kb * AKB >= AKB) block(kb, std::integral_constant<bool, true>{});
+            else block(kb, std::integral_constant<bool, false>{});
         }
     }
     if (!active) return;
@@ -692,6 +797,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         (void)inv;
     }
 }
+
 
 }  // namespace
 
