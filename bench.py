@@ -628,7 +628,7 @@ def main() -> None:
         out["roofline"] = {
             "bound": "mfma", "kernel": "gemm_f32_vit_kernel (v_mfma_f32_16x16x4_f32; all epilogues: patch/qkv/o_proj/up/down)"
                                        if args.precision == 3 else
-                                       "gemm_f32_vit_kernel<EPI, SPLIT = true> (three v_mfma_f32_16x16x32_f16 per product on split operands; "
+                                       "gemm_split_pp_kernel<EPI, ...> (the ping-pong kernel's split-operand form, gemm_f16_8ph.hip: three v_mfma_f32_16x16x32_f16 per product; "
                                        "`achieved` counts the EXECUTED MFMA work = 3 x the algorithmic FLOPs)" if args.precision == 4 else
                                        "gemm_f16_8ph_kernel (all epilogues: patch/qkv/o_proj/up/down)" +
                                        (", MX-fp8 form (F8 = true)" if args.precision == 2 else ""),
