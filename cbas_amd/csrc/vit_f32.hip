@@ -648,6 +648,18 @@ __device__ __forceinline__ float exp_neg(float x) {
 // Measured and removed (r4): a resident form for T <= 256 - one workgroup per (frame, head), one wave per query tile, every
 // key block staged up front (4 x 32 KiB), one barrier, then free-running waves: 71-73 us per layer against this ring's
 // 64-68 (ViT-B/16 batch 64, bit-identical rows): the kernel is not bound by its barriers or by staging K / V twice.
+// exp(d / (ATT_QS ATT_KS)) for d <= 0, finite: exp_neg with the power-of-two score scale folded into its constants (the
+// same roundings: scaling by 2^-6 commutes with each of them) and without the clamp (v_exp_f32 flushes a hugely negative
+// argument to 0, and the correction term is then 0 x finite).
+__device__ __forceinline__ float exp_raw(float d) {
+    constexpr float K_HI = 1.44269504f / (ATT_QS * ATT_KS), K_LO = 1.92596299e-8f / (ATT_QS * ATT_KS);
+    const float t = d * K_HI;
+    float r = fmaf(d, K_HI, -t);
+    r = fmaf(d, K_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147181f, e);
+}
+
 __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                  float* __restrict__ out, int T, int D, int n_heads, int qblocks,
                                                                  float out_scale) {
@@ -690,11 +702,13 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
     };
     stage(0, 0);
 
-    float mrun = -INFINITY, lrun = 0.f;
+    // scores stay in the accumulator's units (x ATT_QS ATT_KS: max and differences scale exactly); the factor is undone
+    // inside the exponential's constant.  Masked scores are a large finite negative, not -inf: exp_raw needs no clamp.
+    constexpr float NEG = -1.0e30f;
+    float mrun = NEG, lrun = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr float S_UNSCALE = 1.0f / (ATT_QS * ATT_KS);
 
     auto block = [&](int kb, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         f32x4 s[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (!FULL && kt >= nkt) { s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
+            if (!FULL && kt >= nkt) { s[kt] = f32x4{NEG, NEG, NEG, NEG}; continue; }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
@@ -717,16 +731,16 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
             }
-            s[kt] = acc * S_UNSCALE;
+            s[kt] = acc;
         }
         if (!FULL) {                                              // only a partial block can hold keys past T
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
+                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = NEG;
         }
-        float bm = -INFINITY;
+        float bm = NEG;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         bm = xor16_max(bm);
         bm = xor32_max(bm);
         const float mnew = fmaxf(mrun, bm);
-        const float alpha = exp_neg(mrun - mnew);
+        const float alpha = exp_raw(mrun - mnew);
         float psum = 0.f;
         f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
 #pragma unroll
@@ -743,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp_neg(s[2 * grp + u][r] - mnew);
+                    const float pv = exp_raw(s[2 * grp + u][r] - mnew);
                     psum += pv;
                     const float x = pv * ATT_PS;
                     const f16 h = (f16)x;
