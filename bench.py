@@ -230,8 +230,12 @@ def files_pass(args, enc, head, rank: int, world: int, device) -> dict:
             recs = cdist.encode_files(paths, enc, head=head, dataset_name="bench", behaviors=names, temperature=1.0)
             cdist.barrier()
             return cdist.max_over_ranks(time.perf_counter() - t0, device), recs
-        once()
-        dt, recs = once()
+        # encode_files reports each clip as the reference does ("Successfully encoded ..." on stdout): stdout carries only
+        # the ONE JSON line of this script, so those go to stderr here
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            once()
+            dt, recs = once()
     finally:
         P.set_project_stamp(None)
     out = None
