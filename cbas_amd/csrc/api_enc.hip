@@ -1289,6 +1289,7 @@ extern "C" int cbas_enc_debug_option(cbas_enc* h, const char* name, int value) {
     if (!h || !name) return cbas_fail(CBAS_EINVAL, "null argument");
     if (!strcmp(name, "rope_lds")) { h->rope_in_lds = value != 0; return CBAS_OK; }
     if (!strcmp(name, "ln_fold")) { h->ln_fold = value != 0; return CBAS_OK; }
+    if (!strcmp(name, "split_kernels")) { vit32_split_debug(value); return CBAS_OK; }       // process-wide (precision 4)
     return cbas_fail(CBAS_EINVAL, "unknown debug option '%s'", name);
 }
 
@@ -1385,7 +1386,7 @@ extern "C" int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int til
     p.split = 1; p.a_scale = 1.f; p.w_scale = 1.f; p.out_scale = 1.f;
     const GemmEpilogue e = (GemmEpilogue)epi;
     auto run = [&]() { return tile < 0 ? launch_gemm_f32_vit(e, p, 0) : launch_gemm_split_pp(e, p, 0); };
-    if (tile < 0) setenv("CBAS_SPLIT_PP", "0", 1);
+    vit32_split_debug(tile < 0 ? 2 : -1);
     gemm_split_pp_debug(tile > 0 ? tile : 0, nullptr);
     int rc = run();
     if (rc) return cbas_fail(CBAS_EINVAL, "split GEMM launch failed (rc=%d)", rc);

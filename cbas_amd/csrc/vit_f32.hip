@@ -348,17 +348,29 @@ int launch_vit32s(const Gemm32VitParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// which precision-4 GEMM forms are in use: bit 0 the ping-pong form (M > 256), bit 1 the skinny form (M <= 256); the
+// rest falls to the 128 x 128 kernels.  -1 = the environment's choice (CBAS_SPLIT_PP / CBAS_SPLIT_SKINNY, default on);
+// set by cbas_enc_debug_option("split_kernels") - process-wide, for the bit-identity tests
+int g_split_forms = -1;
+int split_forms() {
+    static const int env = [] {
+        const char* a = getenv("CBAS_SPLIT_PP");
+        const char* b = getenv("CBAS_SPLIT_SKINNY");
+        return ((!a || a[0] != '0') ? 1 : 0) | ((!b || b[0] != '0') ? 2 : 0);
+    }();
+    return g_split_forms >= 0 ? g_split_forms : env;
+}
+
 template <int EPI>
 int launch_vit32(const Gemm32VitParams& p, hipStream_t stream) {
     if (!p.split) return launch_vit32s<EPI, false>(p, stream);
     if (p.M <= 256) {
-        static const bool skinny = [] { const char* e = getenv("CBAS_SPLIT_SKINNY"); return !e || e[0] != '0'; }();
+        const bool skinny = split_forms() & 2;
         return skinny && EPI != EPI_PATCH ? launch_split_skinny<EPI>(p, stream) : launch_vit32s<EPI, true>(p, stream);
     }
     // large M: the ping-pong kernel's split form (gemm_f16_8ph.hip) where the shape is one of its; all three kernels form
     // the same products in the same order, so the choice does not show in the results
-    static const bool pp = [] { const char* e = getenv("CBAS_SPLIT_PP"); return !e || e[0] != '0'; }();
-    if (pp) {
+    if (split_forms() & 1) {
         const int rc = launch_gemm_split_pp((GemmEpilogue)EPI, p, stream);
         if (rc != -1) return rc;
     }
@@ -816,6 +828,8 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
 }  // namespace
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+void vit32_split_debug(int forms) { g_split_forms = forms; }
 
 int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.N % BN || p.K % BKF || p.lda % 4 || p.ldo % 4) return -1;

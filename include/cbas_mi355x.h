@@ -196,7 +196,11 @@ int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes)
  *               apply mean / rstd in their epilogues; 0: separate LayerNorm kernels.  The two settings agree to fp16 rounding
  *               (both within the 1e-3 CLS bar, both batch-invariant); fp16 path with hidden_size a multiple of 256 only.
  *               Default 0: with two batches in flight the separate kernels already hide under the other lane's GEMMs
- *               (measured +0 ... +1 % for the fold; -5 % of kernel time with a single batch in flight). */
+ *               (measured +0 ... +1 % for the fold; -5 % of kernel time with a single batch in flight).
+ *   "split_kernels"  precision 4, PROCESS-WIDE: which GEMM forms run - bit 0 the ping-pong kernel's split-operand form
+ *               (M > 256, N a multiple of 256), bit 1 the 8-slot-ring skinny form (M <= 256); cleared bits fall to the
+ *               128 x 128 kernels.  -1 (default): both on, or as CBAS_SPLIT_PP=0 / CBAS_SPLIT_SKINNY=0 say.  Every
+ *               setting forms the same products in the same order per output element: bit-identical rows. */
 int cbas_enc_debug_option(cbas_enc* h, const char* name, int value);
 
 /* Bring-up: time the fp16 GEMM kernel alone on random operands (GELU epilogue, M x N x K,

@@ -148,6 +148,28 @@ def test_fp32_batch_invariance_at_the_bench_batch(precision):
         enc.close()
 
 
+def test_precision4_gemm_forms_are_bit_identical():
+    """Precision 4 has three GEMM kernels (the ping-pong kernel's split-operand form for M > 256, the ring-buffered skinny
+    form for the pruned last layer's CLS rows, the 128 x 128 kernels for everything else): every combination gives the
+    same rows, bit for bit, on ViT-B (N multiples of 256) with RoPE, and on the DINOv2 geometry (no RoPE, position table)."""
+    for cfg, hw, seed in ((C.VIT_B16, 224, 7), (C.DINOV2_REG_B14, 224, 8)):
+        enc = make_enc(cfg, hw, 16, 4)
+        try:
+            fr = torch.from_numpy(synth.noise_frames(seed, 16, hw, hw)).cuda()
+            rows = []
+            for forms in (3, 2, 1, 0):
+                enc.debug_option("split_kernels", forms)
+                c16, c32 = enc.encode_u8(fr)
+                torch.cuda.synchronize()
+                rows.append((c16.clone(), c32.clone()))
+            for c16, c32 in rows[1:]:
+                assert torch.equal(c16, rows[0][0]) and torch.equal(c32, rows[0][1])
+            assert torch.isfinite(rows[0][1]).all()
+        finally:
+            enc.debug_option("split_kernels", -1)
+            enc.close()
+
+
 def _e2e(golden_dir, name, cfg, dim, batch, precision=3):
     from cbas_amd.stream import ClipStream
     g = load(golden_dir, name)
