@@ -16,6 +16,8 @@ python bench.py --precision 2 --no-cpu-baseline --files 0 --no-label-exact > $OU
 python bench.py --precision 2 --batch 128 --steps 80 --no-cpu-baseline --files 0 --no-label-exact > $OUT/r04_bench_fp8_b128.json 2>> $OUT/bench.err
 echo "bench lines done"
 python scripts/split_stamps.py 0,256,160 20 > $OUT/r04_split_gemm_stamps.txt 2>&1
+CBAS_SOAK_PRECISION=4 python scripts/soak_files.py 4 $OUT/r04_soak_files_p4.json > $OUT/soak_p4.log 2>&1
+echo "stamps + soak done"
 cd /tmp && export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-host-path --no-gates --files 0 --preroll-seconds 0 --no-label-exact"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_p4_lanes1 -- python3 $GRAFT_REPO_ROOT/bench.py $Q --lanes 1 --precision 4 --steps 80 --warmup 3 > $OUT/bench_prof_p4_lanes1.json 2> $OUT/bench_prof.err

@@ -2,7 +2,7 @@
 twice; every `_cls.h5` / `_outputs.csv` must be byte-identical between the passes and to the same clip run alone through
 encode_infer_file.  Exercises the decode-ahead threads, the page-locked rings, the pipelined clips and the writer threads.
 
-    python scripts/soak_files.py [repeats] [out.json]
+    python scripts/soak_files.py [repeats] [out.json]          (CBAS_SOAK_PRECISION=4: the same through precision 4)
 """
 import hashlib
 import json
@@ -28,7 +28,8 @@ def sha(path):
 def main():
     repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     cfg = C.VIT_B16
-    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(224, 224))
+    precision = int(os.environ.get("CBAS_SOAK_PRECISION", "0"))          # 4: the label-exact mode's kernels under the same load
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(224, 224), precision=precision)
     head = ClassifierLSTMDeltas(768, 9)
     head.load_state_dict(W.synth_head_weights(C.HeadConfig(), 4321))
     head.to("cuda")
@@ -63,7 +64,7 @@ def main():
             q = os.path.join(d, os.path.basename(protos[k]))
             os.symlink(protos[k], q)
             paths.append((int(k), q))
-    res = {"clips": len(paths), "frames": int(sum(lengths[k] for k, _ in paths)), "passes": []}
+    res = {"precision": precision, "clips": len(paths), "frames": int(sum(lengths[k] for k, _ in paths)), "passes": []}
     ok = True
     n_pass = int(os.environ.get("CBAS_SOAK_PASSES", "2"))
 
