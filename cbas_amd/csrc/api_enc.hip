@@ -1363,6 +1363,46 @@ __global__ void checksum_u16(const uint16_t* p, int64_t n, unsigned long long* o
 }
 }  // namespace
 
+// bring-up / tests: a register-only v_mfma_f32_32x32x16_f16 loop on every SIMD (two waves each), queued on `stream` - the
+// neighbour beside which round 4's head kernels returned wrong values in lanes 48-63 (common.h); tests run the head beside it
+namespace {
+__global__ __launch_bounds__(512) void mfma_neighbor_kernel(int iters, float* sink) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    f16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            unsigned x = (t * 64 + i * 8 + e) * 2654435761u; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            a[i][e] = (f16)(((int)(x & 0xffff) - 32768) * (1.0f / 32768.0f));
+            b[i][e] = (f16)(((int)(x >> 16) - 32768) * (1.0f / 32768.0f));
+        }
+    f16v c[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) c[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + r) & 3], b[(i * 2 + r) & 3], c[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) s += c[i][e];
+    if (s == 123.456f) sink[t] = s;
+}
+}  // namespace
+
+extern "C" int cbas_debug_mfma_neighbor(int iters, void* stream) {
+    static float* sink = nullptr;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (!sink) HIP_TRY(hipMalloc(&sink, (size_t)cus * 512 * sizeof(float)));
+    if (iters <= 0) return cbas_fail(CBAS_EINVAL, "iters=%d", iters);
+    hipLaunchKernelGGL(mfma_neighbor_kernel, dim3((unsigned)cus), dim3(512), 0, (hipStream_t)stream, iters, sink);
+    return hipGetLastError() == hipSuccess ? CBAS_OK : cbas_fail(CBAS_EHIP, "mfma_neighbor launch failed");
+}
+
 // precision-4 GEMM (split operands) alone: epi = 1 q|k|v (RoPE), 2 residual, 3 GELU; tile = 0 (planner) / 128 / 160 / 192 / 256
 // rows of the ping-pong form, -1 = the 128 x 128 8-wave kernel; prints the block timeline.  Timing only (random operands).
 extern "C" int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int tile, int iters, float* ms_out) {

@@ -313,6 +313,18 @@ static int infer_range(cbas_head* h, const void* cls_dev, bool half_rows, int64_
     return CBAS_OK;
 }
 
+// bring-up: copy the first `n_floats` floats of a workspace buffer of the last pass to the host (device synchronised first).
+// which: 0 rows32, 1 proj, 2 aug, 3 xl, 4 gin, 5 hout, 6 lin_logits
+extern "C" int cbas_head_debug_read(cbas_head* h, int which, float* host_out, int64_t n_floats) {
+    if (!h || !host_out) return cbas_fail(CBAS_EINVAL, "null argument");
+    const float* src = which == 0 ? h->rows32 : which == 1 ? h->proj : which == 2 ? h->aug : which == 3 ? h->xl : which == 4 ? h->gin
+                       : which == 5 ? h->hout : which == 6 ? h->lin_logits : nullptr;
+    if (!src) return cbas_fail(CBAS_EINVAL, "buffer %d not available", which);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, src, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return CBAS_OK;
+}
+
 extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames,
                                          int64_t first, int64_t count, float temperature, float* probs_dev,
                                          float* logits_dev, void* stream) {

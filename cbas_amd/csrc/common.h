@@ -25,9 +25,48 @@ static __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// BRANCH-FREE elementary functions.  The device library's erff / tanhf choose between two formulas with a divergent branch
+// (s_and_saveexec ... s_or exec).  Round 4 found the head's expand kernel returning wrong values in lanes 48-63 of a wave -
+// the last of the four passes of a wave64 VALU instruction - when waves of ANOTHER kernel on the same CU keep the matrix
+// pipe busy (precision 4's attention kernel; a register-only v_mfma_f32_32x32x16_f16 loop in another process): one wrong
+// LayerNorm row in ~15 % of its runs beside the MFMA loop.  Branch-free erf alone: 0.3 %; with the kernel's LDS read-back
+// of its own earlier writes replaced by registers as well: 0 of 10 170 beside the attention kernel, 0 of 381 beside the loop
+// (scripts/head_beside_encoder.py).  Whether the hardware or the generated code is at fault was not
+// established; inference kernels - which run beside other work - use these forms.
+//   erf: two minimax polynomials (|z| <= 0.9277: z + z P(z^2); beyond: 1 - exp(Q(|z|)), copysign; after N. Juffa's erff),
+//        both evaluated, one selected by v_cndmask; 1.5 ulp against erf in double over [-9, 9] (libm erff: 1.3 ulp)
+static __device__ __forceinline__ float erf_bf(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896341f);
+    float q = fmaf(-5.96761703e-4f, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? __builtin_copysignf(big, a) : q;
+}
 // exact-erf GELU, the reference's ACT2FN["gelu"] / nn.GELU() default
 static __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f));
+}
+//   tanh = sign(x) (1 - e) / (1 + e), e = exp(-2 |x|) with the product's rounding residual carried into the result
+//        (absolute error ~6e-8, all the LSTM's gates need)
+static __device__ __forceinline__ float tanh_bf(float x) {
+    const float v = fmaxf(-2.0f * fabsf(x), -100.f);
+    const float t = v * 1.44269504f;
+    float r = fmaf(v, 1.44269504f, -t);
+    r = fmaf(v, 1.92596299e-8f, r);
+    float e = __builtin_amdgcn_exp2f(t);
+    e = fmaf(e, r * 0.693147181f, e);
+    return __builtin_copysignf((1.0f - e) / (1.0f + e), x);
 }
 
 // Reductions over the lanes l ^ 16 and l ^ 32 (the four lanes that hold one row of an MFMA accumulator tile) through

@@ -46,12 +46,32 @@ __global__ void head_expand_kernel(const float* __restrict__ proj, HeadDims d, c
         return f - r0;
     };
 
-    // pass 1: EMA (torch.lerp(prev, x, alpha) = prev + alpha*(x - prev), alpha < 0.5)
-    float s_prev = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float x = proj[row_of(t) * d.NPROJ + tid];
-        s_prev = (t == 0) ? x : s_prev + alpha * (x - s_prev);
-        sbuf[t * W3 + tid] = s_prev;
+    // passes 1 + 2, fused (r4): EMA (torch.lerp(prev, x, alpha) = prev + alpha*(x - prev), alpha < 0.5) forward in time with
+    // the last three values in registers; stream value (x, dx, ddx with the reflect padding [s2, s1 | s0, s1, ...]) + bias,
+    // GELU, ONE LDS write per t and no LDS read: this column's earlier form wrote the EMA, then read three values back per t -
+    // the part of this kernel that returned wrong values in lanes 48-63 beside MFMA-heavy neighbours (common.h).  Selects,
+    // not branches: `stream` is wave-uniform but the compiler cannot know.
+    {
+        const float bb = b_bott[tid];
+        auto emit = [&](int t, float a, float b, float c) {     // a, b, c = s_t, s_{t-1}, s_{t-2}
+            const float d1 = a - b, d2 = d1 - (b - c);
+            const float v = stream == 0 ? a : (stream == 1 ? d1 : d2);
+            sbuf[t * W3 + tid] = gelu_erf(v + bb);
+        };
+        const float s0 = proj[row_of(0) * d.NPROJ + tid];
+        const float s1 = s0 + alpha * (proj[row_of(1) * d.NPROJ + tid] - s0);
+        const float s2 = s1 + alpha * (proj[row_of(2) * d.NPROJ + tid] - s1);
+        emit(0, s0, s1, s2);
+        emit(1, s1, s0, s1);
+        emit(2, s2, s1, s0);
+        float e2 = s0, e1 = s1, e0 = s2;                        // s_{t-3}, s_{t-2}, s_{t-1} entering t = 3
+        for (int t = 3; t < T; ++t) {
+            const float x = proj[row_of(t) * d.NPROJ + tid];
+            const float e = e0 + alpha * (x - e0);
+            emit(t, e, e0, e1);
+            e2 = e1; e1 = e0; e0 = e;
+        }
+        (void)e2;
     }
     // linear branch: mean over the centre window of EMA(lin1 projection) + bias
     if (tid < d.C) {
@@ -62,21 +82,6 @@ __global__ void head_expand_kernel(const float* __restrict__ proj, HeadDims d, c
             if (t >= d.lo) accum += e;
         }
         lin_logits[w * d.C + tid] = accum / (float)(d.hi - d.lo) + b_lin1[tid];
-    }
-    // pass 2 (own column only, back to front so smaller t stay intact): stream value + bias, GELU
-    const float s0 = sbuf[tid], s1 = sbuf[W3 + tid], s2 = sbuf[2 * W3 + tid];
-    const float bb = b_bott[tid];
-    for (int t = T - 1; t >= 0; --t) {
-        float a, b, c;                  // s_t, s_{t-1}, s_{t-2} with the reflect padding [s2, s1 | s0, s1, ...]
-        if (t >= 3) { a = sbuf[t * W3 + tid]; b = sbuf[(t - 1) * W3 + tid]; c = sbuf[(t - 2) * W3 + tid]; }
-        else if (t == 2) { a = s2; b = s1; c = s0; }
-        else if (t == 1) { a = s1; b = s0; c = s1; }
-        else { a = s0; b = s1; c = s2; }
-        float v;
-        if (stream == 0) v = a;
-        else if (stream == 1) v = a - b;             // dx[1:]
-        else v = (a - b) - (b - c);                  // ddx = dx[1:] - dx[:-1]
-        sbuf[t * W3 + tid] = gelu_erf(v + bb);
     }
     __syncthreads();
     // pass 3: LayerNorm(Bn) per (t, stream) row, one wave per row
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(H * 4) void head_lstm_kernel(const float* __restric
         for (int r = 0; r < 4; ++r) {
             const float ig = sigmoidf_(acc[0][r]);
             const float fg = sigmoidf_(acc[1][r]);
-            const float gg = tanhf(acc[2][r]);
+            const float gg = tanh_bf(acc[2][r]);
             const float og = sigmoidf_(acc[3][r]);
             c[r] = fg * c[r] + ig * gg;
-            const float hn = og * tanhf(c[r]);
+            const float hn = og * tanh_bf(c[r]);
             hbuf[cur ^ 1][4 * g4 + r][unit] = hn;
             if (t >= lo && t < hi && wok[r])
                 hout[((wbase + 4 * g4 + r) * nc + (t - lo)) * (2 * H) + dir * H + unit] = hn;

@@ -33,6 +33,8 @@ __device__ __forceinline__ float drop_scale(unsigned long long key, unsigned lon
     return (unsigned)(mix64(key + idx) >> 40) >= thr ? scale : 0.f;
 }
 
+// training runs alone on the device: it keeps the device library's erff (common.h explains why inference does not)
+__device__ __forceinline__ float gelu_erf_lib(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // d/dx gelu_erf(x) = Phi(x) + x phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(768) void train_expand_fwd_kernel(ExpandArgs a, flo
             Y[e] = y;
             // dropout index = row-major index inside the stream's own (B, T, Bn) tensor
             const unsigned long long di = (unsigned long long)((w * T + t) * Bn + (tid - k * Bn));
-            U[t * F + tid] = gelu_erf(y) * drop_scale(a.key[k], di, a.thr, a.scale);
+            U[t * F + tid] = gelu_erf_lib(y) * drop_scale(a.key[k], di, a.thr, a.scale);
         }
     }
     if (tid < a.C) {                     // linear branch: mean over the centre window of lin1(EMA(x))
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
         for (int t = 0; t < T; ++t) {
             const float y = Y[(w * T + t) * F + tid];
             const unsigned long long di = (unsigned long long)((w * T + t) * Bn + (tid - k * Bn));
-            U[t * F + tid] = gelu_erf(y) * drop_scale(a.key[k], di, a.thr, a.scale);
+            U[t * F + tid] = gelu_erf_lib(y) * drop_scale(a.key[k], di, a.thr, a.scale);
         }
     }
     __syncthreads();
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(768) void train_expand_bwd_kernel(ExpandArgs a, con
 __global__ void gelu_dropout_fwd_kernel(const float* __restrict__ Z, float* __restrict__ out, int64_t n,
                                         unsigned long long key, unsigned thr, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = gelu_erf(Z[i]) * drop_scale(key, (unsigned long long)i, thr, scale);
+    if (i < n) out[i] = gelu_erf_lib(Z[i]) * drop_scale(key, (unsigned long long)i, thr, scale);
 }
 __global__ void gelu_dropout_bwd_kernel(const float* __restrict__ Z, float* __restrict__ d, int64_t n,
                                         unsigned long long key, unsigned thr, float scale) {

@@ -657,16 +657,25 @@ __device__ __forceinline__ float exp_neg(float x) {
     return fmaf(e, r * 0.693147181f, e);
 }
 
-// Built and REMOVED for a reason that is not understood (r4): this kernel with its key blocks written without the per-tile
-// tests (one basic block per full block, 126 VGPRs instead of 100: 67 -> 64 us per layer, bit-identical rows).  Beside
-// that form, the classifier head's recurrent kernel - another stream, co-resident on a CU - returned a few wrong frames in
-// ~25 % of its runs, although the attention kernel only reads (the effect stayed with its LDS-DMA, its P.V half and its
-// stores compiled out; rocBLAS / elementwise kernels beside it were unaffected; no stray write in 2 GiB of canaries; gone
-// when the attention workgroups took the whole LDS).  Found by the file-path soak (CSV files differing from the same clip
-// run alone); this form is clean in the same checks (scripts/head_beside_encoder.py, tests/test_gpu_round4.py).
+// This form (r4: full key blocks without per-tile tests - one basic block per block, four independent MFMA chains - and the
+// score scale folded into the exponential's constants; 67 -> 64 us per layer, rows bit-identical to the earlier form) is
+// the kernel beside which the head's expand kernel first returned wrong values (scripts/head_beside_encoder.py, common.h):
+// it was the trigger, not the fault - it only reads, and the head kernel was the one that needed changing.
 // Measured and removed (r4): a resident form for T <= 256 - one workgroup per (frame, head), one wave per query tile, every
 // key block staged up front (4 x 32 KiB), one barrier, then free-running waves: 71-73 us per layer against this ring's
 // 64-68 (ViT-B/16 batch 64, bit-identical rows): the kernel is not bound by its barriers or by staging K / V twice.
+// exp(d / (ATT_QS ATT_KS)) for d <= 0, finite: exp_neg with the power-of-two score scale folded into its constants (the
+// same roundings: scaling by 2^-6 commutes with each of them) and without the clamp (v_exp_f32 flushes a hugely negative
+// argument to 0, and the correction term is then 0 x finite).
+__device__ __forceinline__ float exp_raw(float d) {
+    constexpr float K_HI = 1.44269504f / (ATT_QS * ATT_KS), K_LO = 1.92596299e-8f / (ATT_QS * ATT_KS);
+    const float t = d * K_HI;
+    float r = fmaf(d, K_HI, -t);
+    r = fmaf(d, K_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147181f, e);
+}
+
 __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                  float* __restrict__ out, int T, int D, int n_heads, int qblocks,
                                                                  float out_scale) {
@@ -709,90 +718,99 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
     };
     stage(0, 0);
 
-    float mrun = -INFINITY, lrun = 0.f;
+    // scores stay in the accumulator's units (x ATT_QS ATT_KS: max and differences scale exactly); the factor is undone
+    // inside the exponential's constant.  Masked scores are a large finite negative, not -inf: exp_raw needs no clamp.
+    constexpr float NEG = -1.0e30f;
+    float mrun = NEG, lrun = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr float S_UNSCALE = 1.0f / (ATT_QS * ATT_KS);
 
+    auto block = [&](int kb, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const char* Kh = smem + (kb & 1) * 4 * SIMG;
+        const char* Kl = Kh + SIMG;
+        const char* Vh = Kl + SIMG;
+        const char* Vl = Vh + SIMG;
+        const int left = T - kb * AKB;
+        const int nkt = FULL ? 4 : (left + 15) >> 4;              // key tiles with at least one real key (wave-uniform)
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (!FULL && kt >= nkt) { s[kt] = f32x4{NEG, NEG, NEG, NEG}; continue; }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
+            }
+            s[kt] = acc;
+        }
+        if (!FULL) {                                              // only a partial block can hold keys past T
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = NEG;
+        }
+        float bm = NEG;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
+        bm = xor16_max(bm);
+        bm = xor32_max(bm);
+        const float mnew = fmaxf(mrun, bm);
+        const float alpha = exp_raw(mrun - mnew);
+        float psum = 0.f;
+        f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp_raw(s[2 * grp + u][r] - mnew);
+                    psum += pv;
+                    const float x = pv * ATT_PS;
+                    const f16 h = (f16)x;
+                    ph[grp][4 * u + r] = h;
+                    pl[grp][4 * u + r] = (f16)(x - (float)h);
+                }
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (!FULL && 2 * s2 >= nkt) continue;                 // both tiles of the group are padding
+            const int krow = 32 * s2 + 4 * g + (li >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = 16 * dt + 4 * (li & 3);
+                union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
+                uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
+                uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
+                ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
+                ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
+            }
+        }
+    };
     for (int kb = 0; kb < nkb; ++kb) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
         __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
         if (kb + 1 < nkb) stage((kb + 1) & 1, kb + 1);
         if (active) {
-            const char* Kh = smem + (kb & 1) * 4 * SIMG;
-            const char* Kl = Kh + SIMG;
-            const char* Vh = Kl + SIMG;
-            const char* Vl = Vh + SIMG;
-            const int left = T - kb * AKB;
-            const int nkt = left >= AKB ? 4 : (left + 15) >> 4;       // key tiles with at least one real key (wave-uniform)
-            f32x4 s[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (kt >= nkt) { s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
-                    const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
-                }
-                s[kt] = acc * S_UNSCALE;
-            }
-            if (kb == nkb - 1) {                                      // only the last block can hold keys past T (scalar branch)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = -INFINITY;
-            }
-            float bm = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
-            bm = xor16_max(bm);
-            bm = xor32_max(bm);
-            const float mnew = fmaxf(mrun, bm);
-            const float alpha = exp_neg(mrun - mnew);
-            float psum = 0.f;
-            f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
-#pragma unroll
-            for (int grp = 0; grp < 2; ++grp)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = exp_neg(s[2 * grp + u][r] - mnew);
-                        psum += pv;
-                        const float x = pv * ATT_PS;
-                        const f16 h = (f16)x;
-                        ph[grp][4 * u + r] = h;
-                        pl[grp][4 * u + r] = (f16)(x - (float)h);
-                    }
-            lrun = lrun * alpha + psum;
-            mrun = mnew;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (2 * s2 >= nkt) continue;                          // both tiles of the group are padding
-                const int krow = 32 * s2 + 4 * g + (li >> 2);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int col = 16 * dt + 4 * (li & 3);
-                    union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
-                    uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
-                    uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
-                    ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
-                    ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
-                }
-            }
+            // a full block (64 real keys: every block but the last) runs without the per-tile tests, so that its four key
+            // tiles are four independent MFMA chains in one basic block; same operations per query either way
+            if (T - kb * AKB >= AKB) block(kb, std::integral_constant<bool, true>{});
+            else block(kb, std::integral_constant<bool, false>{});
         }
     }
     if (!active) return;

@@ -203,6 +203,18 @@ int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes)
  *               setting forms the same products in the same order per output element: bit-identical rows. */
 int cbas_enc_debug_option(cbas_enc* h, const char* name, int value);
 
+/* Bring-up / tests (round 4).
+ *   cbas_debug_gemm_split_bench: precision 4's GEMM alone on random split operands (epi 1 q|k|v, 2 residual, 3 GELU; tile 0 =
+ *       planner, 128 / 160 / 192 / 256 rows of the ping-pong form, -1 = the 128 x 128 kernel), prints its block timeline.
+ *   cbas_debug_mfma_neighbor: queue a register-only v_mfma_f32_32x32x16_f16 loop (every SIMD, two waves each, `iters` rounds
+ *       of 8 MFMAs) on `stream`: the neighbour beside which the head is checked for bit-stability
+ *       (scripts/head_beside_encoder.py).
+ *   cbas_head_debug_read: copy the first n_floats of a head workspace buffer of the last pass to the host
+ *       (0 rows32, 1 proj, 2 aug, 3 xl, 4 gin, 5 hout, 6 lin_logits); the device is synchronised first. */
+int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int tile, int iters, float* ms_out);
+int cbas_debug_mfma_neighbor(int iters, void* stream);
+int cbas_head_debug_read(cbas_head* h, int which, float* host_out, int64_t n_floats);
+
 /* Bring-up: time the fp16 GEMM kernel alone on random operands (GELU epilogue, M x N x K,
  * tile: 0 auto, 1 128x128, 2 256x128, 3 128x256, 4 256x256, 5+ experimental variants) and return a
  * position-weighted checksum of the fp16 output, so tile variants can be compared bit for bit. */

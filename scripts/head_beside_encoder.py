@@ -1,17 +1,26 @@
-"""Does anything the encoder runs perturb a head inference that runs BESIDE it (another stream, same device)?
+"""Does anything that runs BESIDE a head inference (another stream, same device) change its result?
 The head classifies fixed rows in a loop on its own stream and every result is compared, bit for bit, with the result
-of the idle device, while the main thread loops encoder passes cut off after a given stage (0 patch, 1 LayerNorm,
-2 q|k|v, 3 attention, 4 o_proj, 5 LayerNorm, 6 up, 7 down of layer 0; -1 = the whole encoder).
+of the idle device, while the main thread keeps the device busy with (a) encoder passes cut off after a given stage
+(0 patch, 1 LayerNorm, 2 q|k|v, 3 attention, 4 o_proj, 5 LayerNorm, 6 up, 7 down of layer 0; -1 = the whole encoder) or
+(b) a register-only v_mfma_f32_32x32x16_f16 loop on every SIMD (cbas_debug_mfma_neighbor; stage "mfma").
 
     python scripts/head_beside_encoder.py [precision [seconds [out.json]]]      (CBAS_SPLIT_FORMS=<0..3>: precision 4's GEMM forms)
 
-Why this exists (round 4): a rewrite of precision 4's attention kernel (same arithmetic; key blocks without per-tile
-branches, 126 VGPRs instead of 100) made ~25 % of concurrent head runs return a few frames with probabilities off by
-~1e-2, although that kernel only READS (the effect persisted with its LDS-DMA, its P.V half and its stores compiled
-out), rocBLAS / elementwise torch kernels beside it were unaffected, and canary buffers showed no stray write.  It needed
-co-residence on a CU (gone when the attention workgroups took the whole LDS) and the victim was the head's recurrent
-kernel.  The cause was not found; the kernel was reverted (the soak of the file path, which found it, is byte-identical
-again) and tests/test_gpu_round4.py runs this check for precisions 0 and 4."""
+Why this exists (round 4).  The precision-4 soak of the file path reported CSV files that differed, in single frames by
+~1e-2, from the same clips run alone, while the encoder's rows were identical.  Narrowed down on the GPU:
+  * the head's result changed only when a NEW form of precision 4's attention kernel ran beside it (bit-identical rows, one
+    basic block per key block, 126 VGPRs) - although that kernel only reads: the effect stayed with its LDS-DMA, its P.V
+    half and its stores compiled out; rocBLAS / elementwise torch kernels beside it stayed bit-stable; 2 GiB of canary
+    buffers saw no stray write; it needed co-residence on a CU;
+  * the same happened beside a pure v_mfma_f32_32x32x16_f16 loop in ANOTHER PROCESS (not beside 16x16x32 loops);
+  * the wrong values were always in `head_expand_kernel`: ONE LayerNorm input row of the third stream, columns 48-63 or
+    112-127 = lanes 48-63 (the last of a wave64 VALU instruction's four passes) of that stream's two waves, holding values
+    that match none of the kernel's intermediate quantities;
+  * what removed it: no divergent (EXEC-masked) code in the kernel's arithmetic - the device library's erff picks one of two
+    formulas with a branch; branch-free erf: 15 % -> 0.3 % of runs beside the MFMA loop - and no LDS read-back of values the
+    same thread wrote a few iterations earlier (the EMA written in one pass and re-read three at a time in the next; now
+    carried in registers): 0 of 10 170 runs beside the attention kernel, 0 of 381 beside the MFMA loop.
+Whether the hardware or the generated code is at fault was not established.  tests/test_gpu_round4.py runs this check."""
 import json, os, sys, threading, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +29,7 @@ from cbas_amd.encoder import DinoEncoder  # noqa: E402
 from cbas_amd.head import ClassifierLSTMDeltas  # noqa: E402
 
 
-def run(precision: int, seconds: float, stages=((0, 3), (0, 5), (0, 7), (-1, -1)), forms: int = -1):
+def run(precision: int, seconds: float, stages=((0, 3), (0, 5), (0, 7), (-1, -1), ("mfma", 0)), forms: int = -1):
     cfg = C.VIT_B16
     enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(224, 224), precision=precision)
     if precision == 4:
@@ -52,7 +61,11 @@ def run(precision: int, seconds: float, stages=((0, 3), (0, 5), (0, 7), (-1, -1)
             t0, k = time.time(), 0
             try:
                 while time.time() - t0 < seconds:
-                    _lib.check(enc._lib.cbas_enc_debug_forward_u8(enc._h, fr.data_ptr(), 64, 224, 224, 224 * 224, 224, 1, layer, stage), "debug_forward")
+                    if layer == "mfma":                   # ~10 ms of dense 32x32x16 MFMAs per launch on the default stream
+                        _lib.check(enc._lib.cbas_debug_mfma_neighbor(20000, None), "mfma_neighbor")
+                        torch.cuda.synchronize()
+                    else:
+                        _lib.check(enc._lib.cbas_enc_debug_forward_u8(enc._h, fr.data_ptr(), 64, 224, 224, 224 * 224, 224, 1, layer, stage), "debug_forward")
                     k += 1
             finally:
                 stop.set()

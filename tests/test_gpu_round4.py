@@ -375,15 +375,15 @@ def test_encode_files_local_writes_two_ranks_real_kernels(tmp_path):
 @pytest.mark.parametrize("precision", [0, 4])
 def test_head_beside_the_encoder_is_bit_stable(precision):
     """The file path runs the head on its own stream while the encoder's lanes run the next batches.  A head inference
-    beside encoder passes (cut after attention, after the MLP, and whole) must return the bytes it returns on an idle
-    device: round 4's file-path soak found an attention-kernel variant beside which the head's recurrent kernel did not
-    (scripts/head_beside_encoder.py tells the story); this is the guard."""
+    beside encoder passes (cut after attention, after the MLP, and whole) and beside a dense 32x32x16 MFMA loop must
+    return the bytes it returns on an idle device: round 4's file-path soak found neighbours beside which the head's
+    expand kernel did not (scripts/head_beside_encoder.py tells the story); this is the guard."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "head_beside_encoder", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "head_beside_encoder.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    res = mod.run(precision, 1.5, stages=((0, 3), (0, 7), (-1, -1)))
+    res = mod.run(precision, 1.5, stages=((0, 3), (0, 7), (-1, -1), ("mfma", 0)))
     print(res)
     for st in res:
         assert st["head_runs"] > 50, st
