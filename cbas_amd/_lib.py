@@ -80,6 +80,7 @@ SIGNATURES = {
     "cbas_debug_mfma_neighbor": (c_int, [c_int, c_void_p]),
     "cbas_debug_gemm_split_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float)]),
     "cbas_head_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_debug_gemm_split_compare": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int64)]),
     "cbas_enc_profile": (c_int, [c_void_p, c_int]),
     "cbas_enc_profile_read": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double),
                                       c_int]),

@@ -1476,6 +1476,70 @@ extern "C" int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int til
     return CBAS_OK;
 }
 
+// precision-4 GEMM forms against each other on the same random split operands: the ping-pong form at `tile` rows (0 = planner)
+// and the 128 x 128 kernels; n_diff = output 32-bit words that differ (the forms promise 0).  epi as above; the residual
+// form starts both runs from the same x.
+namespace {
+__global__ void count_diff_u32(const uint32_t* a, const uint32_t* b, int64_t n, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(out, c);
+}
+}  // namespace
+extern "C" int cbas_debug_gemm_split_compare(int M, int N, int K, int epi, int tile, int64_t* n_diff) {
+    if (M <= 0 || N % 256 || K % 64 || epi < 1 || epi > 3 || !n_diff) return cbas_fail(CBAS_EINVAL, "bad split GEMM compare shape");
+    if (epi == 1 && (N % 3 || (N / 3) % 64)) return cbas_fail(CBAS_EINVAL, "q|k|v compare needs N = 3 D, D a multiple of 64");
+    float *A = nullptr, *Wt = nullptr, *o1 = nullptr, *o2 = nullptr, *x0 = nullptr, *bias = nullptr, *rope = nullptr;
+    unsigned long long* cnt = nullptr;
+    const int64_t no = (int64_t)M * N;
+    HIP_TRY(hipMalloc(&A, (int64_t)M * K * 4));
+    HIP_TRY(hipMalloc(&Wt, (int64_t)N * K * 4));
+    HIP_TRY(hipMalloc(&o1, no * 4)); HIP_TRY(hipMalloc(&o2, no * 4)); HIP_TRY(hipMalloc(&x0, no * 4));
+    HIP_TRY(hipMalloc(&bias, (int64_t)N * 4 * 2));
+    HIP_TRY(hipMalloc(&rope, 2 * 196 * 64 * 4));
+    HIP_TRY(hipMalloc(&cnt, 8));
+    HIP_TRY(hipMemset(cnt, 0, 8));
+    auto fill = [&](float* p, int64_t n_f16, unsigned seed, float sc) {
+        hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)((n_f16 + 255) / 256)), dim3(256), 0, 0, (f16*)p, n_f16, seed, sc);
+    };
+    fill(A, (int64_t)M * K * 2, 1u, 1.0f);
+    fill(Wt, (int64_t)N * K * 2, 2u, 0.05f);
+    // fp32 side data: bias / lambda, x, cos / sin - any finite numbers do (random halves widened by the conversion kernel)
+    f16* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (no > 2 * 196 * 64 ? no : 2 * 196 * 64) * 2));
+    auto fill32 = [&](float* p, int64_t n, unsigned seed, float sc) {
+        hipLaunchKernelGGL(fill_random_f16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, tmp, n, seed, sc);
+        return launch_f16_to_f32(tmp, p, n, 0);
+    };
+    if (fill32(bias, (int64_t)N * 2, 3u, 0.5f) || fill32(x0, no, 4u, 2.0f) || fill32(rope, 2 * 196 * 64, 5u, 1.0f)) return cbas_fail(CBAS_EHIP, "fill failed");
+    // the tables are angles.tile(2) ([tf]:190): columns d and d + 32 of a row hold the same number - the tile epilogue relies on it
+    HIP_TRY(hipMemcpy2D(rope + 32, 64 * 4, rope, 64 * 4, 32 * 4, 2 * 196, hipMemcpyDeviceToDevice));
+    Gemm32VitParams p{};
+    p.A = A; p.lda = K; p.W = Wt; p.M = M; p.N = N; p.K = K; p.bias = bias; p.lambda = bias + N; p.ldo = N;
+    p.tokens_per_frame = 201; p.n_prefix = 5; p.patches_per_frame = 196; p.rope_cos = rope; p.rope_sin = rope + 196 * 64; p.D = N / 3;
+    p.split = 1; p.a_scale = 2.f; p.w_scale = 4.f; p.out_scale = 4.f;
+    const GemmEpilogue e = (GemmEpilogue)epi;
+    int rc = 0;
+    for (int form = 0; form < 2 && !rc; ++form) {
+        float* o = form ? o2 : o1;
+        HIP_TRY(hipMemcpy(o, x0, no * 4, hipMemcpyDeviceToDevice));
+        p.out = o;
+        if (form == 0) { gemm_split_pp_debug(tile > 0 ? tile : 0, nullptr); vit32_split_debug(3); }
+        else vit32_split_debug(0);
+        rc = launch_gemm_f32_vit(e, p, 0);
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    gemm_split_pp_debug(0, nullptr);
+    vit32_split_debug(-1);
+    if (rc) return cbas_fail(CBAS_EINVAL, "split GEMM launch failed (rc=%d)", rc);
+    hipLaunchKernelGGL(count_diff_u32, dim3(1024), dim3(256), 0, 0, (const uint32_t*)o1, (const uint32_t*)o2, no, cnt);
+    unsigned long long hc = 0;
+    HIP_TRY(hipMemcpy(&hc, cnt, 8, hipMemcpyDeviceToHost));
+    *n_diff = (int64_t)hc;
+    hipFree(A); hipFree(Wt); hipFree(o1); hipFree(o2); hipFree(x0); hipFree(bias); hipFree(rope); hipFree(cnt); hipFree(tmp);
+    return CBAS_OK;
+}
+
 extern "C" int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
                                      unsigned long long* checksum_out) {
     // tile >= 100: residual epilogue (o_proj/down_proj style, fp32 in/out) with tile id = tile - 100;

@@ -212,6 +212,9 @@ int cbas_enc_debug_option(cbas_enc* h, const char* name, int value);
  *   cbas_head_debug_read: copy the first n_floats of a head workspace buffer of the last pass to the host
  *       (0 rows32, 1 proj, 2 aug, 3 xl, 4 gin, 5 hout, 6 lin_logits); the device is synchronised first. */
 int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int tile, int iters, float* ms_out);
+/* the same GEMM through the ping-pong / skinny forms and through the 128 x 128 kernels on the same random operands:
+ * n_diff = 32-bit output words that differ (0 by construction: same products in the same order) */
+int cbas_debug_gemm_split_compare(int M, int N, int K, int epi, int tile, int64_t* n_diff);
 int cbas_debug_mfma_neighbor(int iters, void* stream);
 int cbas_head_debug_read(cbas_head* h, int which, float* host_out, int64_t n_floats);
 

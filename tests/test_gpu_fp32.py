@@ -170,6 +170,23 @@ def test_precision4_gemm_forms_are_bit_identical():
             enc.close()
 
 
+def test_precision4_gemm_forms_shape_sweep():
+    """The split-operand GEMM alone, ping-pong / skinny forms against the 128 x 128 kernels on the same random operands:
+    every epilogue (q|k|v with RoPE and head-split output, residual, GELU with split output), every tile height, row counts
+    around the tile and the M <= 256 boundaries, the ViT-B and ViT-L projection shapes - 0 differing output words."""
+    import ctypes
+    from cbas_amd import _lib
+    lib = _lib.load()
+    n = ctypes.c_int64()
+    shapes = [(768, 768, 2), (2304, 768, 1), (3072, 768, 3), (768, 3072, 2), (1024, 4096, 2), (4096, 1024, 3), (3072, 1024, 1)]
+    for M in (64, 201, 256, 257, 300, 511, 1000, 3216, 12864, 12865):
+        for N, K, epi in shapes:
+            tiles = (0,) if M <= 256 else ((0, 128, 160, 192, 256) if M in (257, 1000, 12865) else (0,))
+            for tile in tiles:
+                _lib.check(lib.cbas_debug_gemm_split_compare(M, N, K, epi, tile, ctypes.byref(n)), "cbas_debug_gemm_split_compare")
+                assert n.value == 0, (M, N, K, epi, tile, n.value)
+
+
 def _e2e(golden_dir, name, cfg, dim, batch, precision=3):
     from cbas_amd.stream import ClipStream
     g = load(golden_dir, name)
