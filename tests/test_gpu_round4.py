@@ -386,5 +386,5 @@ def test_head_beside_the_encoder_is_bit_stable(precision):
     res = mod.run(precision, 1.5, stages=((0, 3), (0, 7), (-1, -1), ("mfma", 0)))
     print(res)
     for st in res:
-        assert st["head_runs"] > 50, st
+        assert st["head_runs"] > 10, st
         assert st["head_runs_differing"] == 0, st
