@@ -38,6 +38,13 @@
 // per row, 2 KiB per tile pair) ride along as one extra 4-byte LDS-DMA per wave issued with the A-sub1 sub-tile, and are
 // read with the fragments they belong to.
 //
+// Split-operand form (SPLIT = true, precision 4; gemm_split_pp_kernel): operands are fp32 values stored as fp16 hi | lo halves,
+// 32 k-values per 128-byte LDS row (vit32_epilogue.h describes the format) - again the same rows, swizzle, staging schedule and
+// fragment reads; a lane's two 16-byte reads are the hi and the lo halves of its 8 k-values, a phase issues w_lo a_hi, w_hi a_lo,
+// w_hi a_hi per accumulator (24 MFMAs where the fp16 form has 16: the loop is MFMA-bound at 256 rows with a third of the
+// staging per MFMA), and the epilogues are the fp32-schedule ones of vit32_epilogue.h, bounced through the same per-wave LDS
+// scratch.  The fp16 / MX-fp8 instantiations are untouched by it (if constexpr; same instruction streams as before).
+//
 // Reference arithmetic replaced: the same nn.Linear calls as gemm_f16.hip ([tf] modeling_dinov3_vit.py
 // :307-309, :331, :356-357).
 #include <stdlib.h>
