@@ -388,3 +388,51 @@ def test_head_beside_the_encoder_is_bit_stable(precision):
     for st in res:
         assert st["head_runs"] > 10, st
         assert st["head_runs_differing"] == 0, st
+
+
+@pytest.mark.parametrize("precision", [0, 4])
+def test_pipelined_clips_write_the_bytes_of_clips_run_alone(tmp_path, precision):
+    """A short form of scripts/soak_files.py (the test that found round 4's head / neighbour interference) at the real
+    model size: ragged clips through `encode_files` - decode-ahead, both encoder lanes, the head on its own stream beside
+    them, clip n + 1 starting under clip n's tail - must write the files the same clips write when run alone."""
+    import hashlib
+    from cbas_amd import dist as cdist, pipeline as P
+    from cbas_amd.encoder import DinoEncoder
+    from cbas_amd.head import ClassifierLSTMDeltas
+    cfg = C.VIT_B16
+    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(224, 224), precision=precision)
+    head = ClassifierLSTMDeltas(768, 9)
+    head.load_state_dict(W.synth_head_weights(C.HeadConfig(), 4321))
+    head.to("cuda")
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    try:
+        base = synth.cage_frames(3, 300, 224, 224)
+        lengths = [700, 1, 513, 31, 1030, 128]
+        protos = []
+        for k, n in enumerate(lengths):
+            p = tmp_path / f"proto{k}.npy"
+            np.save(p, base[(np.arange(n) * (k + 1)) % 300])
+            protos.append(str(p))
+        alone = []
+        for k, p in enumerate(protos):
+            d = tmp_path / f"alone{k}"
+            d.mkdir()
+            q = d / os.path.basename(p)
+            os.symlink(p, q)
+            h5, csv = P.encode_infer_file(enc, head, str(q), "soak", NAMES)
+            alone.append((sha(h5), sha(csv)))
+        paths = []
+        for r in range(3):
+            for k in np.random.default_rng(r).permutation(len(protos)):
+                d = tmp_path / f"r{r}_{k}"
+                d.mkdir()
+                q = d / os.path.basename(protos[k])
+                os.symlink(protos[k], q)
+                paths.append((int(k), str(q)))
+        recs = cdist.encode_files([q for _, q in paths], enc, head=head, dataset_name="soak", behaviors=NAMES)
+        for (k, _q), r in zip(paths, recs):
+            assert r["status"] == "ok", r
+            assert (sha(r["cls_file"]), sha(r["csv_file"])) == alone[k], (precision, k, lengths[k])
+    finally:
+        head.close()
+        enc.close()
