@@ -52,6 +52,8 @@ def run(precision: int, seconds: float, stages=((0, 3), (0, 5), (0, 7), (-1, -1)
                 s2.synchronize()
                 res[0] += 1
                 res[1] += int(not torch.equal(o, ref))
+    if precision == 2:                                    # MX-fp8 has no debug taps: whole passes and the MFMA loop only
+        stages = tuple(st for st in stages if st[0] in (-1, "mfma"))
     out = []
     try:
         for layer, stage in stages:
@@ -63,6 +65,9 @@ def run(precision: int, seconds: float, stages=((0, 3), (0, 5), (0, 7), (-1, -1)
                 while time.time() - t0 < seconds:
                     if layer == "mfma":                   # ~10 ms of dense 32x32x16 MFMAs per launch on the default stream
                         _lib.check(enc._lib.cbas_debug_mfma_neighbor(20000, None), "mfma_neighbor")
+                        torch.cuda.synchronize()
+                    elif layer == -1:                     # the whole encoder (every precision)
+                        enc.encode_u8(fr, want_f32=False)
                         torch.cuda.synchronize()
                     else:
                         _lib.check(enc._lib.cbas_enc_debug_forward_u8(enc._h, fr.data_ptr(), 64, 224, 224, 224 * 224, 224, 1, layer, stage), "debug_forward")
