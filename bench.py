@@ -647,7 +647,9 @@ def main() -> None:
                               "share": round(v["ms"] * 1e-3 / dt_events, 4)} for k, v in prof.items()},
         }
         # the committed PMC passes cover the headline workload in its default and fp32 modes; other workloads report null
-        pmc_file, pmc_key, pmc_cmd = {0: ("pmc_traffic.json", "gemm_f16_hbm_bytes_per_launch", "scripts/quick_perf.py vitb16 64 3"),
+        pmc_file, pmc_key, pmc_cmd = {0: ("pmc_traffic.json", "gemm_f16_hbm_bytes_per_launch",
+                                          "bench.py itself, one batch in flight, 2 + 20 steps, frames resident "
+                                          "(scripts/profile_pmc_bench.sh)"),
                                       3: ("r04_pmc_traffic_fp32.json", "gemm_f32_hbm_bytes_per_launch",
                                           "scripts/quick_perf.py vitb16 64 3 224 3")}.get(args.precision, (None, None, None))
         pmc = os.path.join(HERE, "profiles", pmc_file) if pmc_file else None
@@ -656,7 +658,7 @@ def main() -> None:
                 out["roofline"]["traffic"] = json.load(open(pmc)).get(pmc_key)
                 out["roofline"]["traffic_source"] = (f"profiles/{pmc_file}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
                                                      f"{pmc_cmd} - the same encoder, batch and kernels as this command, frames "
-                                                     "resident (scripts/profile_round.sh, scripts/profile_r04.sh); not measured in this run")
+                                                     "resident; taken in its own runs, not in this one")
             except Exception:  # noqa: BLE001
                 pass
     if world == 1 and not args.no_cpu_baseline and not hung:

@@ -22,7 +22,7 @@ constexpr int M_ROWS = 13056, N_ROWS = 768, PITCH = 1536, KT = 12, TILES_N = 3;
 
 // pieces (64 rows x 128 B = 8 KB) per K-tile on each path; LDSR = ds_read_b128 per lane per K-tile of the slot that has landed
 // (24 = what a 128 x 64 wave tile reads: 16 KB of A + 8 KB of B fragments per wave)
-template <int DMA_A, int DMA_B, int REG_A, int REG_B, int LDSR = 0>
+template <int DMA_A, int DMA_B, int REG_A, int REG_B, int LDSR = 0, int FRAG = 0>
 __global__ __launch_bounds__(512) void stream_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, int steps, int TILES_M,
                                                      unsigned long long* out, unsigned* sink) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
@@ -43,13 +43,22 @@ __global__ __launch_bounds__(512) void stream_kernel(const uint8_t* __restrict__
 #pragma unroll
         for (int p = 0; p < DMA_B; ++p)
             __builtin_amdgcn_global_load_lds(GLB_PTR(b + (size_t)(p & 3) * 64 * PITCH), LDS_PTR(ring + (DMA_A + p) * 8192), 16, 0, 0);
+        if (FRAG) {
+            // MFMA fragment layout, 8 waves as 4 (M) x 2 (N): wave w owns rows 64 (w >> 1) ... + 63 of the tile and asks for them
+            // itself - load p: row tile p >> 1, k-half p & 1; lane -> row lane & 15, 16 bytes at 16 (lane >> 4) + 64 (p & 1):
+            // 16 rows x 64 bytes per instruction, every line asked for by two loads of this wave and two of its neighbour
+            const uint8_t* af = A + (size_t)((tile / TILES_N) * 256 + (t >> 7) * 64 + (t & 15)) * PITCH + kt * 128 + ((t >> 4) & 3) * 16;
 #pragma unroll
-        for (int p = 0; p < REG_A; ++p) regs[p] = *reinterpret_cast<const uint4*>(a + (size_t)(p & 3) * 64 * PITCH);
+            for (int p = 0; p < REG_A; ++p) regs[p] = *reinterpret_cast<const uint4*>(af + (size_t)(p >> 1) * 16 * PITCH + (p & 1) * 64);
+        } else {
+#pragma unroll
+            for (int p = 0; p < REG_A; ++p) regs[p] = *reinterpret_cast<const uint4*>(a + (size_t)(p & 3) * 64 * PITCH);
+        }
 #pragma unroll
         for (int p = 0; p < REG_B; ++p) regs[REG_A + p] = *reinterpret_cast<const uint4*>(b + (size_t)(p & 3) * 64 * PITCH);
     };
     auto read_lds = [&](int it) {
-        const uint8_t* slot = lds + (it & 1) * 65536 + (t & 63) * 16 + ((t >> 6) & 1) * 32768;
+        const uint8_t* slot = lds + (it & 1) * 65536 + (t & 63) * 16 + ((t >> 6) & 1) * (LDSR <= 16 ? 16384 : 32768);
 #pragma unroll
         for (int j = 0; j < LDSR; ++j) {
             const uint4 v = *reinterpret_cast<const uint4*>(slot + j * 1024);
@@ -82,9 +91,9 @@ __global__ __launch_bounds__(512) void stream_kernel(const uint8_t* __restrict__
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[wg * 512 + t] = acc.x + lds[t];
 }
 
-template <int DA, int DB, int RA, int RB, int LR = 0>
+template <int DA, int DB, int RA, int RB, int LR = 0, int FR = 0>
 static void run(const char* what, const uint8_t* A, const uint8_t* B, int steps, int tiles_m, unsigned long long* d_out, unsigned* sink, int n_cu) {
-    auto k = stream_kernel<DA, DB, RA, RB, LR>;
+    auto k = stream_kernel<DA, DB, RA, RB, LR, FR>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -101,7 +110,7 @@ static void run(const char* what, const uint8_t* A, const uint8_t* B, int steps,
     double cyc = 0, wall = 0;
     for (int i = 0; i < n_cu; ++i) { cyc += h[i * 2]; wall += h[i * 2 + 1]; }
     cyc /= n_cu; wall /= n_cu;
-    const double bytes = (double)steps * KT * (DA + DB + RA + RB) * 8192.0;
+    const double bytes = (DA + DB + RA + RB) ? (double)steps * KT * (DA + DB + RA + RB) * 8192.0 : (double)steps * KT * LR * 8192.0;
     printf("{\"mode\": \"%s\", \"dma_pieces\": %d, \"reg_pieces\": %d, \"bytes_per_cu\": %.0f, \"B_per_cycle_per_cu\": %.2f, "
            "\"GB_s_per_cu\": %.1f, \"chip_TB_s\": %.2f, \"core_clock_GHz\": %.3f, \"kernel_ms\": %.3f}\n",
            what, DA + DB, RA + RB, bytes, bytes / cyc, bytes / (wall * 10.0), bytes * n_cu / (ms * 1e-3) / 1e12, cyc / (wall * 10.0), ms);
@@ -127,10 +136,13 @@ int main(int argc, char** argv) {
     printf("{\"device\": \"%s\", \"cus\": %d, \"tile_steps\": %d, \"k_tiles_per_step\": %d, \"a_rows\": %d}\n", prop.name, n_cu, steps, KT, tiles_m * 256);
     run<4, 4, 0, 0>("A and B by LDS-DMA (the kernels' staging)", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<4, 4, 0, 0, 24>("A and B by LDS-DMA while every wave reads 24 KB of fragments per K-tile from the landed slot (ds_read_b128)", A, B, steps, tiles_m, d_out, sink, n_cu);
+    run<0, 0, 0, 0, 24>("no operand traffic: only the 24 KB of fragment reads per wave per K-tile (bytes = LDS bytes read)", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<4, 4, 0, 0, 12>("the same with 12 KB of fragment reads per wave", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<0, 0, 4, 4>("A and B by global_load_dwordx4 into registers", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<0, 4, 4, 0>("B by LDS-DMA, A into registers", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<0, 4, 8, 0>("B by LDS-DMA, A into registers twice (both waves of a row group)", A, B, steps, tiles_m, d_out, sink, n_cu);
+    run<0, 4, 8, 0, 0, 1>("B by LDS-DMA, A into registers in MFMA fragment layout by the wave that uses it (64 KB asked for, 32 KB distinct)", A, B, steps, tiles_m, d_out, sink, n_cu);
+    run<0, 4, 8, 0, 16, 1>("the same while every wave reads its 16 KB of B fragments per K-tile from the landed slot", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<0, 4, 0, 0>("B by LDS-DMA alone (half the bytes)", A, B, steps, tiles_m, d_out, sink, n_cu);
     run<0, 0, 4, 0>("A into registers alone (half the bytes)", A, B, steps, tiles_m, d_out, sink, n_cu);
     return 0;
