@@ -292,6 +292,18 @@ def main() -> None:
                          "management settling - and reads several % under a 157-step run of the same binary")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line: the JSON record.  Libraries print banners of their own at the file-descriptor level
+    # (RCCL's version block when the communicator is created, gloo's "[Gloo] Rank ..." lines, the reference-style
+    # "Successfully encoded ..." messages of the file path), so descriptor 1 points at stderr for the whole run - on every
+    # rank - and the record is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
+
     # RCCL ("nccl") on a real multi-GPU node.  CBAS_DIST_BACKEND=gloo rehearses the multi-rank control
     # flow on a box with fewer GPUs than ranks (ranks then share devices; the gather goes through host
     # memory) - a rehearsal, not a measurement.
@@ -665,9 +677,8 @@ def main() -> None:
         out["cpu_baseline"] = cpu_baseline(args.model, args.hw, args.cpu_frames, 8)
     if hung:
         out["error"] = "files_path pass hung (watchdog fired): gates and cpu_baseline skipped, exit code 3"
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     if hung:
-        sys.stdout.flush()
         os._exit(3)
 
 
