@@ -304,6 +304,23 @@ def main() -> None:
         sys.stdout.flush()
         os.write(real_stdout, (line + "\n").encode())
 
+    # Whole-run watchdog: the N > 1 passes contain RCCL collectives and point-to-point transfers that no multi-GPU node has
+    # run yet.  If the run has not finished in time, rank 0 still writes a line that says so (value null) and every rank
+    # exits non-zero, instead of hanging until the caller's own limit with nothing on stdout.
+    import threading
+    run_limit = float(os.environ.get("CBAS_BENCH_TIMEOUT", "1500"))
+    finished = threading.Event()
+
+    def _run_watchdog():
+        if finished.wait(run_limit):
+            return
+        if int(os.environ.get("RANK", "0")) == 0:
+            emit(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                             "error": f"bench.py did not finish within {run_limit:.0f} s (CBAS_BENCH_TIMEOUT); exit code 4"}))
+        os._exit(4)
+    threading.Thread(target=_run_watchdog, name="cbas-bench-watchdog", daemon=True).start()
+
     # RCCL ("nccl") on a real multi-GPU node.  CBAS_DIST_BACKEND=gloo rehearses the multi-rank control
     # flow on a box with fewer GPUs than ranks (ranks then share devices; the gather goes through host
     # memory) - a rehearsal, not a measurement.
@@ -549,6 +566,7 @@ def main() -> None:
         if hung:
             sys.stdout.flush()
             os._exit(3)
+        finished.set()
         return
     frames_total = K * B * world
     hbm_value = frames_total / dt
@@ -677,6 +695,7 @@ def main() -> None:
         out["cpu_baseline"] = cpu_baseline(args.model, args.hw, args.cpu_frames, 8)
     if hung:
         out["error"] = "files_path pass hung (watchdog fired): gates and cpu_baseline skipped, exit code 3"
+    finished.set()
     emit(json.dumps(out))
     if hung:
         os._exit(3)
