@@ -308,7 +308,7 @@ def main() -> None:
     # run yet.  If the run has not finished in time, rank 0 still writes a line that says so (value null) and every rank
     # exits non-zero, instead of hanging until the caller's own limit with nothing on stdout.
     import threading
-    run_limit = float(os.environ.get("CBAS_BENCH_TIMEOUT", "900"))
+    run_limit = float(os.environ.get("CBAS_BENCH_TIMEOUT", str(900 + 0.05 * args.steps)))     # long --steps runs get their time
     finished = threading.Event()
 
     def _run_watchdog():
