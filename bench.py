@@ -35,8 +35,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# RCCL shares device buffers between the ranks' processes through dmabuf IPC handles on this pool's driver; the HSA runtime reads
+# the switch when it starts, i.e. before the first device call below (cbas_amd.dist sets it too, but later than set_device)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
