@@ -1,5 +1,9 @@
 """ctypes binding of libcbas_mi355x.so (declared in include/cbas_mi355x.h).
 
+With CBAS_BUILD_DEBUG=1 in the environment the DEBUG build is loaded instead (libcbas_mi355x_debug.so: the same library
+plus the bring-up / test entry points of include/cbas_mi355x_debug.h).  The GPU test suite and scripts/ set it; the
+product library exports none of those symbols and `require_debug()` says so when one is asked for.
+
 There is no CPU fallback: if the library is missing it is built with hipcc; if that fails, or a
 call returns a non-zero code, a ``RuntimeError`` carrying ``cbas_last_error()`` is raised.
 """
@@ -68,19 +72,6 @@ SIGNATURES = {
     "cbas_fused_rows_ready": (c_int64, [c_void_p, c_int32]),
     "cbas_enc_set_lanes": (c_int, [c_void_p, c_int]),
     "cbas_enc_set_prune_last_layer": (c_int, [c_void_p, c_int]),
-    "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
-                                          c_int, c_int]),
-    "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
-    "cbas_enc_debug_option": (c_int, [c_void_p, C.c_char_p, c_int]),
-    "cbas_debug_overlap": (c_int, [c_int, c_int, C.POINTER(c_float)]),
-    "cbas_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float),
-                                      C.POINTER(C.c_ulonglong)]),
-    "cbas_debug_gemm_f8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p]),
-    "cbas_debug_mfma_neighbor": (c_int, [c_int, c_void_p]),
-    "cbas_debug_gemm_split_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float)]),
-    "cbas_head_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
-    "cbas_debug_gemm_split_compare": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int64)]),
     "cbas_enc_profile": (c_int, [c_void_p, c_int]),
     "cbas_enc_profile_read": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double),
                                       c_int]),
@@ -108,13 +99,45 @@ SIGNATURES = {
     "cbas_device_info": (c_int, [c_int, C.c_char_p, c_int, C.POINTER(c_int32), C.POINTER(c_int64)]),
 }
 
+# include/cbas_mi355x_debug.h: exported by libcbas_mi355x_debug.so only (CBAS_BUILD_DEBUG=1)
+DEBUG_SIGNATURES = {
+    "cbas_enc_debug_forward_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                                          c_int, c_int]),
+    "cbas_enc_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_enc_debug_option": (c_int, [c_void_p, C.c_char_p, c_int]),
+    "cbas_debug_overlap": (c_int, [c_int, c_int, C.POINTER(c_float)]),
+    "cbas_debug_gemm_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float),
+                                      C.POINTER(C.c_ulonglong)]),
+    "cbas_debug_gemm_f8": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "cbas_debug_mfma_neighbor": (c_int, [c_int, c_void_p]),
+    "cbas_debug_gemm_split_bench": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float)]),
+    "cbas_head_debug_read": (c_int, [c_void_p, c_int, c_void_p, c_int64]),
+    "cbas_debug_gemm_split_compare": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_int64)]),
+    "cbas_head_debug_expand_module": (c_int, [c_void_p, C.c_char_p, C.c_char_p]),
+    "cbas_head_debug_expand_repeat": (c_int, [c_void_p, c_int, c_int]),
+    "cbas_head_debug_expand_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "cbas_debug_build": (c_int, []),
+}
+
 ENC_SLOTS = 3
-EXPECTED_ABI = 9          # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
+EXPECTED_ABI = 10         # CBAS_ABI_VERSION of include/cbas_mi355x.h these ctypes structures mirror
 PROF_CATS = ["patch_gemm", "layernorm", "qkv_gemm", "attention", "oproj_gemm", "up_gemm", "down_gemm", "other"]
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    return _build.lib_path()
+
+
+def is_debug() -> bool:
+    """True when the loaded (or to-be-loaded) library is the debug build."""
+    return _build.debug_selected()
+
+
+def require_debug(what: str) -> None:
+    if not is_debug():
+        raise RuntimeError(f"{what} is a bring-up / test entry point (include/cbas_mi355x_debug.h): set CBAS_BUILD_DEBUG=1 "
+                           "before the first cbas_amd call to load libcbas_mi355x_debug.so (python -m cbas_amd.build --debug)")
 
 
 def load(build_if_missing: bool = True):
@@ -126,12 +149,13 @@ def load(build_if_missing: bool = True):
         # torch ships its own libamdhip64; import it FIRST so this library binds to the same HIP
         # runtime (two runtimes in one process do not see the GPU: "no ROCm-capable device")
         import torch  # noqa: F401
-        path = _build.LIB_PATH
+        path = _build.lib_path()
+        debug = _build.debug_selected()
         if not os.path.exists(path):
             if not build_if_missing:
-                raise RuntimeError(f"{path} is missing; run `python -m cbas_amd.build`")
+                raise RuntimeError(f"{path} is missing; run `python -m cbas_amd.build{' --debug' if debug else ''}`")
             _build.build_library()
-        elif _build._stale():
+        elif _build._stale(debug):
             # sources newer than the binary: rebuild when asked to (CBAS_AUTOBUILD=1), otherwise say so -
             # a silent stale binary is how an edited kernel "does nothing"
             if os.environ.get("CBAS_AUTOBUILD") == "1":
@@ -141,7 +165,7 @@ def load(build_if_missing: bool = True):
                 print(f"cbas_amd: {path} is older than its sources; run `python -m cbas_amd.build` "
                       "(or set CBAS_AUTOBUILD=1)", file=sys.stderr)
         lib = C.CDLL(path)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + (list(DEBUG_SIGNATURES.items()) if debug else []):
             fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

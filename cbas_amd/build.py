@@ -1,6 +1,18 @@
-"""Build libcbas_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build the native library in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m cbas_amd.build [--force] [--verbose]
+    python -m cbas_amd.build [--force] [--verbose] [--debug | --all] [--no-asm-check]
+
+Two variants of the same sources:
+
+  libcbas_mi355x.so         the PRODUCT: exactly the entry points of include/cbas_mi355x.h (what a CBAS installation,
+                            bench.py and __graft_entry__.smoke() load)
+  libcbas_mi355x_debug.so   the product + the bring-up / test / harness entry points of include/cbas_mi355x_debug.h
+                            (-DCBAS_BUILD_DEBUG=1; what the GPU test suite and scripts/ load: CBAS_BUILD_DEBUG=1 in the
+                            environment selects it, see _lib.py)
+
+Sources that never mention CBAS_BUILD_DEBUG compile to the same object for both and are compiled once.  After the link,
+`asmcheck` disassembles the device code of the kernels that run beside other work and reports the instruction patterns
+DESIGN.md section 4 says to keep out of them; its report is written next to the library (asmcheck_report.json).
 """
 from __future__ import annotations
 
@@ -13,10 +25,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libcbas_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
+DEBUG_LIB_NAME = "libcbas_mi355x_debug.so"
+DEBUG_LIB_PATH = os.path.join(HERE, DEBUG_LIB_NAME)
 SOURCES = ["gemm_f16.hip", "gemm_f16_8ph.hip", "gemm_f16_skinny.hip", "gemm_f32.hip", "vit_f32.hip", "vit_kernels.hip", "head_kernels.hip", "head_train_kernels.hip",
            "api_enc.hip", "api_head.hip", "api_head_train.hip", "api_fused.hip", "host_text.cpp", "host_mjpeg.cpp", "host_pixels.cpp"]
+DEBUG_ONLY_SOURCES = ["api_debug.hip"]            # harnesses: never in the product
 EXTRA_FLAGS = {"host_mjpeg.cpp": ["-mavx2"]}      # host-only file: 8-lane integer vectors in the inverse DCT (checked at run time)
 ARCH = "gfx950"
+HEADERS = [os.path.join(HERE, "..", "include", "cbas_mi355x.h"), os.path.join(HERE, "..", "include", "cbas_mi355x_debug.h")]
+
+
+def debug_selected() -> bool:
+    """CBAS_BUILD_DEBUG=1 in the environment: load / build the debug variant."""
+    return os.environ.get("CBAS_BUILD_DEBUG", "0") not in ("", "0")
+
+
+def lib_path(debug: bool | None = None) -> str:
+    return DEBUG_LIB_PATH if (debug_selected() if debug is None else debug) else LIB_PATH
 
 
 def _hipcc() -> str:
@@ -26,34 +51,45 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _deps() -> list:
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + HEADERS
+
+
+def _stale(debug: bool | None = None) -> bool:
+    path = lib_path(debug)
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "cbas_mi355x.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(path)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB_PATH
+def _mentions_debug(src: str) -> bool:
+    with open(os.path.join(CSRC, src), "r", errors="replace") as f:
+        return "CBAS_BUILD_DEBUG" in f.read()
+
+
+def build_library(force: bool = False, verbose: bool = False, debug: bool | None = None, asm_check: bool = True) -> str:
+    debug = debug_selected() if debug is None else debug
+    out_path = lib_path(debug)
+    if not force and not _stale(debug):
+        return out_path
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
               "-Wno-unused-result", "-I", CSRC]
+    headers = [os.path.join(CSRC, hname) for hname in os.listdir(CSRC) if hname.endswith(".h")] + HEADERS
     objs = []
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+    for src in SOURCES + (DEBUG_ONLY_SOURCES if debug else []):
+        variant = debug and (src in DEBUG_ONLY_SOURCES or _mentions_debug(src))
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + (".debug.o" if variant else ".o"))
         objs.append(obj)
         srcp = os.path.join(CSRC, src)
-        headers = [os.path.join(CSRC, hname) for hname in os.listdir(CSRC) if hname.endswith(".h")]
-        headers.append(os.path.join(HERE, "..", "include", "cbas_mi355x.h"))
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
                 and all(os.path.getmtime(obj) > os.path.getmtime(hp) for hp in headers)):
             continue
-        cmd = [hipcc, *common, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
+        cmd = [hipcc, *common, *EXTRA_FLAGS.get(src, []), *(["-DCBAS_BUILD_DEBUG=1"] if variant else []), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -63,15 +99,29 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{outp}")
         if verbose and outp.strip():
             print(outp)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}",
+           "-o", out_path, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB_PATH
+    if asm_check and not debug:
+        from . import asmcheck
+        asmcheck.check_library(out_path, verbose=verbose, enforce=False)      # TODO(r5): enforce once the rule is settled
+    return out_path
+
+
+def build_all(force: bool = False, verbose: bool = False) -> list:
+    return [build_library(force, verbose, debug=False), build_library(force, verbose, debug=True)]
 
 
 if __name__ == "__main__":
-    path = build_library(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
-    print(path)
+    force = "--force" in sys.argv
+    verbose = "--verbose" in sys.argv or "-v" in sys.argv
+    check = "--no-asm-check" not in sys.argv
+    if "--all" in sys.argv:
+        for path in [build_library(force, verbose, debug=False, asm_check=check), build_library(force, verbose, debug=True)]:
+            print(path)
+    else:
+        print(build_library(force, verbose, debug=True if "--debug" in sys.argv else None, asm_check=check))

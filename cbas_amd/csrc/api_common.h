@@ -4,6 +4,12 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/cbas_mi355x.h"
+#ifndef CBAS_BUILD_DEBUG
+#define CBAS_BUILD_DEBUG 0
+#endif
+#if CBAS_BUILD_DEBUG
+#include "../../include/cbas_mi355x_debug.h"      // bring-up / test entry points: debug build only
+#endif
 
 extern thread_local char g_cbas_err[512];
 

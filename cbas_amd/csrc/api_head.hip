@@ -30,7 +30,50 @@ struct cbas_head {
     int64_t win_cap = 0;             // windows per pass the per-window buffers hold
     int64_t proj_rows_cap = 0;       // rows of `proj` (explicit windows: w*T; sliding: w + T)
     int64_t rows32_cap = 0;          // rows of `rows32` (sliding mode with half-precision input only)
+#if CBAS_BUILD_DEBUG
+    hipModule_t expand_module = nullptr;     // cbas_head_debug_expand_module: a probe kernel run in place of head_expand_kernel
+    hipFunction_t expand_fn = nullptr;
+    // cbas_head_debug_expand_repeat: the expand stage launched `expand_repeat` times per pass, every launch's rows compared
+    // with a reference copy on the device; differing rows are appended to `cap` ([cap_rows][2 + Bn] floats)
+    int expand_repeat = 1;
+    float* aug_ref = nullptr;                // [win_cap * T * NS * Bn], captured by mode 1
+    int64_t aug_ref_elems = 0;
+    int capture_mode = 0;                    // 1: the next pass copies its rows to aug_ref, 2: compare
+    unsigned long long* dbg_counts = nullptr;   // [0] launches compared, [1] launches with a differing row, [2] differing rows, [3] rows captured
+    float* cap = nullptr;
+    int cap_rows = 0;
+#endif
 };
+
+#if CBAS_BUILD_DEBUG
+namespace {
+// one wave per (window, t, stream) row of Bn floats: bitwise compare with the reference copy; a differing row is appended
+// (row index, launch number, Bn values) to the capture buffer while it has room
+__global__ void debug_compare_rows_kernel(const float* __restrict__ aug, const float* __restrict__ ref, int64_t n_rows, int Bn,
+                                          unsigned long long* counts, float* cap, int cap_rows, unsigned launch_no) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counts[0], 1ull);
+    if (row >= n_rows) return;
+    bool diff = false;
+    for (int k = lane; k < Bn; k += 64)
+        diff |= __float_as_uint(aug[row * Bn + k]) != __float_as_uint(ref[row * Bn + k]);
+    const unsigned long long any = __ballot(diff);
+    if (!any) return;
+    unsigned long long slot = 0;
+    if (lane == 0) {
+        atomicAdd(&counts[2], 1ull);
+        if (atomicAdd(&counts[4 + (launch_no & 1023)], 1ull) == 0) atomicAdd(&counts[1], 1ull);    // first differing row of this launch
+        slot = atomicAdd(&counts[3], 1ull);
+    }
+    slot = __shfl(slot, 0, 64);
+    if (slot >= (unsigned long long)cap_rows) return;
+    float* o = cap + slot * (2 + Bn);
+    if (lane == 0) { o[0] = (float)row; o[1] = (float)launch_no; }
+    for (int k = lane; k < Bn; k += 64) o[2 + k] = aug[row * Bn + k];
+}
+}  // namespace
+#endif
 
 namespace {
 
@@ -46,8 +89,50 @@ int64_t head_weights_count(const cbas_head_config& c) {
 int run_chunk(cbas_head* h, int64_t nw, int sliding, int64_t w0, int64_t r0, int64_t n_frames, float temperature,
               float* probs, float* logits, float* latent, hipStream_t st) {
     const HeadDims& d = h->d;
+#if CBAS_BUILD_DEBUG
+    {   // root-cause probe (scripts/expand_rootcause.py): optionally a separately built code object in place of the library's
+        // kernel, optionally launched several times per pass with every launch's rows compared with a reference on the device
+        HeadDims dd = d;
+        const float *proj = h->proj, *b_bott = h->b_bott, *ln_w = h->ln_w, *ln_b = h->ln_b, *b_lin1 = h->b_lin1;
+        float *aug = h->aug, *lin_logits = h->lin_logits;
+        void* args[] = {&proj, &dd, &b_bott, &ln_w, &ln_b, &b_lin1, &sliding, &w0, &r0, &n_frames, &aug, &lin_logits};
+        const unsigned threads = (unsigned)(d.NS * d.Bn);
+        const size_t lds = (size_t)d.T * threads * sizeof(float);
+        if (h->expand_fn && lds > 64 * 1024)
+            return cbas_fail(CBAS_EINVAL, "expand probe: %zu bytes of LDS (64 KiB at most through a module launch)", lds);
+        const int64_t elems = nw * d.T * d.NS * d.Bn;
+        const bool compare = h->capture_mode == 2 && h->aug_ref && elems <= h->aug_ref_elems;
+        const int reps = compare ? h->expand_repeat : 1;
+        for (int rep = 0; rep < reps; ++rep) {
+            if (h->expand_fn)
+                HIP_TRY(hipModuleLaunchKernel(h->expand_fn, (unsigned)nw, 1, 1, threads, 1, 1, (unsigned)lds, st, args, nullptr));
+            else
+                LAUNCH_TRY(launch_head_expand(h->proj, d, h->b_bott, h->ln_w, h->ln_b, h->b_lin1, nw, sliding, w0, r0, n_frames,
+                                              h->aug, h->lin_logits, st));
+            if (compare) {
+                static unsigned launch_no = 0;
+                const int64_t n_rows = nw * d.T * d.NS;
+                HIP_TRY(hipMemsetAsync(h->dbg_counts + 4 + (launch_no & 1023), 0, sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(debug_compare_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, h->aug, h->aug_ref,
+                                   n_rows, d.Bn, h->dbg_counts, h->cap, h->cap_rows, launch_no);
+                ++launch_no;
+            }
+        }
+        if (h->capture_mode == 1) {
+            if (elems > h->aug_ref_elems) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (h->aug_ref) (void)hipFree(h->aug_ref);
+                h->aug_ref = nullptr; h->aug_ref_elems = 0;
+                HIP_TRY(hipMalloc(&h->aug_ref, (size_t)elems * sizeof(float)));
+                h->aug_ref_elems = elems;
+            }
+            HIP_TRY(hipMemcpyAsync(h->aug_ref, h->aug, (size_t)elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    }
+#else
     LAUNCH_TRY(launch_head_expand(h->proj, d, h->b_bott, h->ln_w, h->ln_b, h->b_lin1, nw, sliding, w0, r0, n_frames,
                                   h->aug, h->lin_logits, st));
+#endif
     Gemm32Params g{};
     g.A = h->aug; g.lda = d.NS * d.Bn; g.W = h->w_lin0; g.bias = h->b_lin0; g.out = h->xl; g.ldo = d.L0;
     g.M = nw * d.T; g.N = d.L0; g.N_alloc = d.L0; g.K = d.NS * d.Bn;
@@ -138,6 +223,12 @@ extern "C" void cbas_head_destroy(cbas_head* h) {
     void* bufs[] = {h->wbuf, h->rows32, h->proj, h->aug, h->xl, h->gin, h->hout, h->lin_logits, h->hfull};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+#if CBAS_BUILD_DEBUG
+    if (h->expand_module) (void)hipModuleUnload(h->expand_module);
+    if (h->aug_ref) (void)hipFree(h->aug_ref);
+    if (h->dbg_counts) (void)hipFree(h->dbg_counts);
+    if (h->cap) (void)hipFree(h->cap);
+#endif
     delete h;
 }
 
@@ -313,6 +404,7 @@ static int infer_range(cbas_head* h, const void* cls_dev, bool half_rows, int64_
     return CBAS_OK;
 }
 
+#if CBAS_BUILD_DEBUG
 // bring-up: copy the first `n_floats` floats of a workspace buffer of the last pass to the host (device synchronised first).
 // which: 0 rows32, 1 proj, 2 aug, 3 xl, 4 gin, 5 hout, 6 lin_logits
 extern "C" int cbas_head_debug_read(cbas_head* h, int which, float* host_out, int64_t n_floats) {
@@ -324,6 +416,58 @@ extern "C" int cbas_head_debug_read(cbas_head* h, int which, float* host_out, in
     HIP_TRY(hipMemcpy(host_out, src, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return CBAS_OK;
 }
+
+// root-cause probe (round 5): run `kernel_name` of the code object at `hsaco_path` in place of head_expand_kernel on this handle
+extern "C" int cbas_head_debug_expand_module(cbas_head* h, const char* hsaco_path, const char* kernel_name) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null head handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->expand_module) { (void)hipModuleUnload(h->expand_module); h->expand_module = nullptr; h->expand_fn = nullptr; }
+    if (!hsaco_path) return CBAS_OK;
+    if (!kernel_name) return cbas_fail(CBAS_EINVAL, "kernel_name is NULL");
+    HIP_TRY(hipModuleLoad(&h->expand_module, hsaco_path));
+    hipError_t e = hipModuleGetFunction(&h->expand_fn, h->expand_module, kernel_name);
+    if (e != hipSuccess) {
+        (void)hipModuleUnload(h->expand_module); h->expand_module = nullptr; h->expand_fn = nullptr;
+        return cbas_fail(CBAS_EHIP, "no kernel '%s' in %s: %s", kernel_name, hsaco_path, hipGetErrorString(e));
+    }
+    return CBAS_OK;
+}
+
+// amplification for the probe: mode 1 = the next pass (run it on an idle device) copies its expand output to a reference
+// buffer; mode 2 = every pass launches the probe kernel `repeat` times and compares every launch's rows with that reference on
+// the device (differing rows are captured); mode 0 = off.  cbas_head_debug_expand_stats: counts[0..3] = launches compared,
+// launches with a differing row, differing rows, rows offered to the capture buffer; rows_out receives up to max_rows captured
+// rows of 2 + Bn floats (row index = (window * T + t) * NS + stream, launch number, the row); reset != 0 clears the counters.
+extern "C" int cbas_head_debug_expand_repeat(cbas_head* h, int mode, int repeat) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null head handle");
+    if (mode < 0 || mode > 2 || repeat < 1) return cbas_fail(CBAS_EINVAL, "mode %d / repeat %d", mode, repeat);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!h->dbg_counts) {
+        HIP_TRY(hipMalloc(&h->dbg_counts, (4 + 1024) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(h->dbg_counts, 0, (4 + 1024) * sizeof(unsigned long long)));
+        h->cap_rows = 512;
+        HIP_TRY(hipMalloc(&h->cap, (size_t)h->cap_rows * (2 + h->d.Bn) * sizeof(float)));
+    }
+    h->capture_mode = mode;
+    h->expand_repeat = repeat;
+    return CBAS_OK;
+}
+
+extern "C" int cbas_head_debug_expand_stats(cbas_head* h, uint64_t* counts4, float* rows_out, int max_rows, int reset) {
+    if (!h || !counts4) return cbas_fail(CBAS_EINVAL, "null argument");
+    if (!h->dbg_counts) return cbas_fail(CBAS_ESTATE, "cbas_head_debug_expand_repeat was not called");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(counts4, h->dbg_counts, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    int n = (int)(counts4[3] < (uint64_t)h->cap_rows ? counts4[3] : (uint64_t)h->cap_rows);
+    if (n > max_rows) n = max_rows;
+    if (rows_out && n > 0) HIP_TRY(hipMemcpy(rows_out, h->cap, (size_t)n * (2 + h->d.Bn) * sizeof(float), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dbg_counts, 0, (4 + 1024) * sizeof(unsigned long long)));
+    return CBAS_OK;
+}
+#endif
 
 extern "C" int cbas_head_infer_f16_range(cbas_head* h, const uint16_t* cls_f16_dev, int64_t n_frames,
                                          int64_t first, int64_t count, float temperature, float* probs_dev,

@@ -654,7 +654,7 @@ int launch_split_pp(const GemmParams& p, const Gemm32VitParams& sp, int main_pan
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int g_split_tile = 0;                          // bring-up (gemm_split_pp_debug): forced tile height, stamps buffer
+int g_split_tile = 0;                          // bring-up (gemm_split_pp_set_tile): forced tile height, stamps buffer
 unsigned long long* g_split_stamps = nullptr;
 
 template <int EPI>
@@ -674,7 +674,7 @@ int launch_split_pp_epi(const GemmParams& p, const Gemm32VitParams& sp, hipStrea
 
 }  // namespace
 
-void gemm_split_pp_debug(int tile, unsigned long long* stamps) { g_split_tile = tile; g_split_stamps = stamps; }
+void gemm_split_pp_set_tile(int tile, unsigned long long* stamps) { g_split_tile = tile; g_split_stamps = stamps; }
 
 // precision 4, large M: -1 when the shape is not this kernel's (the caller keeps its 128 x 128 kernels for those)
 int launch_gemm_split_pp(GemmEpilogue epi, const Gemm32VitParams& sp_in, hipStream_t stream) {

@@ -172,8 +172,8 @@ struct Gemm32VitParams {
 int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream);
 // precision 4, M > 256, N % 256 == 0: the ping-pong kernel's split-operand form (gemm_f16_8ph.hip); -1 = not its shape
 int launch_gemm_split_pp(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream);
-void vit32_split_debug(int forms);   // bring-up: which precision-4 GEMM forms run (bit 0 ping-pong, bit 1 skinny; -1 = environment)
-void gemm_split_pp_debug(int tile, unsigned long long* stamps);   // bring-up: forced tile height (0 = planner), block timeline stamps
+void vit32_split_set_forms(int forms);   // bring-up: which precision-4 GEMM forms run (bit 0 ping-pong, bit 1 skinny; -1 = environment)
+void gemm_split_pp_set_tile(int tile, unsigned long long* stamps);   // bring-up: forced tile height (0 = planner), block timeline stamps
 // uint8 pixels -> A[n*P][256] fp32 = float(double(pixel) / 255.0), the reference's cbas.py:431 value bit for bit
 // (+ prefix rows of x, as launch_im2col_u8)
 // split != 0 (precision 4): A in the split hi | lo format of vit_f32.hip

@@ -833,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
 
-void vit32_split_debug(int forms) { g_split_forms = forms; }
+void vit32_split_set_forms(int forms) { g_split_forms = forms; }
 
 int launch_gemm_f32_vit(GemmEpilogue epi, const Gemm32VitParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.N % BN || p.K % BKF || p.lda % 4 || p.ldo % 4) return -1;

@@ -259,7 +259,9 @@ class DinoEncoder:
         _lib.check(self._lib.cbas_enc_set_prune_last_layer(self._h, int(bool(enable))), "cbas_enc_set_prune_last_layer")
 
     def debug_option(self, name: str, value: int) -> None:
-        """Bring-up / tests: switch an implementation detail whose settings are bit-identical (cbas_enc_debug_option)."""
+        """Bring-up / tests: switch an implementation detail whose settings are bit-identical (cbas_enc_debug_option;
+        debug build of the library only)."""
+        _lib.require_debug("cbas_enc_debug_option")
         _lib.check(self._lib.cbas_enc_debug_option(self._h, name.encode(), int(value)), "cbas_enc_debug_option")
 
     def wait_stream(self, slot: int) -> None:
@@ -293,6 +295,7 @@ class DinoEncoder:
 
     # -- bring-up taps -----------------------------------------------------------------------------
     def debug_tap(self, frames: torch.Tensor, stop_layer: int, stop_stage: int, which: int, channel: int = 1):
+        _lib.require_debug("cbas_enc_debug_forward_u8")
         n, H, W = frames.shape[:3]
         if frames.dim() == 4:
             Cn = frames.shape[3]

@@ -51,7 +51,7 @@ extern "C" {
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
 
-#define CBAS_ABI_VERSION   9
+#define CBAS_ABI_VERSION   10
 
 typedef struct cbas_enc  cbas_enc;
 typedef struct cbas_head cbas_head;
@@ -179,64 +179,9 @@ int cbas_enc_set_lanes(cbas_enc* h, int n_lanes);
  * bit-identical).  enable = 0 restores the full last layer (used by the tests that prove the identity). */
 int cbas_enc_set_prune_last_layer(cbas_enc* h, int enable);
 
-/* Bring-up/debug: run the forward pass only up to (layer, stage) and copy an internal buffer to
- * the host.  stage: 0 embeddings (x), then per layer 1 LN1(h16) 2 QKV(qkv16) 3 attention(h16)
- * 4 o_proj residual (x) 5 LN2 (h16) 6 up_proj+GELU (u16) 7 down_proj residual (x).
- * which: 0 x f32 (rows,D)  1 h16 (rows,D)  2 qkv16 (rows,3D)  3 u16 (rows,F); rows = n*T. */
-int cbas_enc_debug_forward_u8(cbas_enc* h, const uint8_t* frames_dev, int n, int height, int width,
-                              int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
-                              int stop_layer, int stop_stage);
-int cbas_enc_debug_read(cbas_enc* h, int which, void* host_out, int64_t n_bytes);
-
-/* Bring-up / tests: switch an implementation detail of the handle.  Options:
- *   "rope_lds"  1 (default): the q|k|v epilogue reads the RoPE angles, factorised by axis, from LDS; 0: from the [P][64]
- *               table in global memory ([tf]:96-121, 168-200 either way).  Bit-identical results.
- *   "ln_fold"   1: LayerNorm ([tf]:404, 410) is folded into the GEMMs around it - o_proj / down_proj write a fp16 copy of
- *               the residual stream and per-row statistics, q|k|v / up_proj run on it with gamma folded into their weights and
- *               apply mean / rstd in their epilogues; 0: separate LayerNorm kernels.  The two settings agree to fp16 rounding
- *               (both within the 1e-3 CLS bar, both batch-invariant); fp16 path with hidden_size a multiple of 256 only.
- *               Default 0: with two batches in flight the separate kernels already hide under the other lane's GEMMs
- *               (measured +0 ... +1 % for the fold; -5 % of kernel time with a single batch in flight).
- *   "split_kernels"  precision 4, PROCESS-WIDE: which GEMM forms run - bit 0 the ping-pong kernel's split-operand form
- *               (M > 256, N a multiple of 256), bit 1 the 8-slot-ring skinny form (M <= 256); cleared bits fall to the
- *               128 x 128 kernels.  -1 (default): both on, or as CBAS_SPLIT_PP=0 / CBAS_SPLIT_SKINNY=0 say.  Every
- *               setting forms the same products in the same order per output element: bit-identical rows. */
-int cbas_enc_debug_option(cbas_enc* h, const char* name, int value);
-
-/* Bring-up / tests (round 4).
- *   cbas_debug_gemm_split_bench: precision 4's GEMM alone on random split operands (epi 1 q|k|v, 2 residual, 3 GELU; tile 0 =
- *       planner, 128 / 160 / 192 / 256 rows of the ping-pong form, -1 = the 128 x 128 kernel), prints its block timeline.
- *   cbas_debug_mfma_neighbor: queue a register-only v_mfma_f32_32x32x16_f16 loop (every SIMD, two waves each, `iters` rounds
- *       of 8 MFMAs) on `stream`: the neighbour beside which the head is checked for bit-stability
- *       (scripts/head_beside_encoder.py).
- *   cbas_head_debug_read: copy the first n_floats of a head workspace buffer of the last pass to the host
- *       (0 rows32, 1 proj, 2 aug, 3 xl, 4 gin, 5 hout, 6 lin_logits); the device is synchronised first. */
-int cbas_debug_gemm_split_bench(int M, int N, int K, int epi, int tile, int iters, float* ms_out);
-/* the same GEMM through the ping-pong / skinny forms and through the 128 x 128 kernels on the same random operands:
- * n_diff = 32-bit output words that differ (0 by construction: same products in the same order) */
-int cbas_debug_gemm_split_compare(int M, int N, int K, int epi, int tile, int64_t* n_diff);
-int cbas_debug_mfma_neighbor(int iters, void* stream);
-int cbas_head_debug_read(cbas_head* h, int which, float* host_out, int64_t n_floats);
-
-/* Bring-up: time the fp16 GEMM kernel alone on random operands (GELU epilogue, M x N x K,
- * tile: 0 auto, 1 128x128, 2 256x128, 3 128x256, 4 256x256, 5+ experimental variants) and return a
- * position-weighted checksum of the fp16 output, so tile variants can be compared bit for bit. */
-int cbas_debug_gemm_bench(int M, int N, int K, int tile, int iters, float* ms_out,
-                          unsigned long long* checksum_out);
-
-/* Bring-up: how kernels of two compute lanes share the chip.  Concurrently, each on its own stream, `iters` launches of
- * bit 0 the up projection (12 864 x 3072 x 768, GELU), bit 1 LayerNorm (12 864 x 768), bit 2 attention (64 x 201 tokens,
- * 12 heads), bit 3 the down projection (residual epilogue).  ms_out[0..3] = average milliseconds per launch of each
- * component on its stream, ms_out[4] = wall milliseconds of the whole run (scripts/overlap_kernels.py). */
-int cbas_debug_overlap(int mode, int iters, float* ms_out);
-
-/* Bring-up / tests: the MX-fp8 GEMM of precision 2 in isolation.  A (M x K) and W (N x K) fp32 host matrices are
- * quantised with the library's block quantiser (e4m3 elements, one E8M0 scale per 32 k-elements), multiplied by the
- * fp8 kernel (tile: 0 = the shape's default, 13..16 = a fixed ping-pong tile) and out = A_q W_q^T (M x N fp32) is
- * returned together with the quantised bytes and scales ([K/128][round_up(M,256)] resp. [K/128][N] dwords, byte b of
- * a dword = block b of that 128-wide K-tile).  N % 256 == 0, K % 256 == 0. */
-int cbas_debug_gemm_f8(int M, int N, int K, int tile, const float* A_host, const float* W_host, float* out_host,
-                       uint8_t* A8_host, uint32_t* Asc_host, uint8_t* W8_host, uint32_t* Wsc_host);
+/* Bring-up, test and measurement-harness entry points (stage taps, implementation switches, stand-alone GEMM
+ * harnesses, the MFMA neighbour) are NOT part of this boundary: include/cbas_mi355x_debug.h, built only into
+ * libcbas_mi355x_debug.so (python -m cbas_amd.build --debug). */
 
 /* Per-kernel timing for benchmarks: while enabled, every kernel launch of the forward pass is
  * bracketed by HIP events on the launch stream.  cbas_enc_profile_read synchronises the device

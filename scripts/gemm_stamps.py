@@ -2,6 +2,8 @@
 on the four encoder shapes at M = 12 864 (ViT-B/16, 64 frames), each with its own epilogue, through cbas_debug_gemm_bench's
 stamp option (tile = 1000 + 100 residual | 200 q|k|v | 0 GELU, + 500 MX-fp8; tile id 0 = the planner's choice).
 usage: python scripts/gemm_stamps.py [iters [M]]            (the library prints the stamp lines on stdout)"""
+import os as _os
+_os.environ.setdefault("CBAS_BUILD_DEBUG", "1")      # bring-up entry points: the debug build of the library
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbas_amd import _lib

@@ -21,6 +21,8 @@ Why this exists (round 4).  The precision-4 soak of the file path reported CSV f
     same thread wrote a few iterations earlier (the EMA written in one pass and re-read three at a time in the next; now
     carried in registers): 0 of 10 170 runs beside the attention kernel, 0 of 381 beside the MFMA loop.
 Whether the hardware or the generated code is at fault was not established.  tests/test_gpu_round4.py runs this check."""
+import os as _os
+_os.environ.setdefault("CBAS_BUILD_DEBUG", "1")      # bring-up entry points: the debug build of the library
 import json, os, sys, threading, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -6,6 +6,8 @@ along (no library counterpart through torch).
 
     python scripts/lib_gemm_ref.py [out.json]        -> profiles/r04_lib_gemm_ref.json (ViT-B at M = 12 864, ViT-L at M = 32 928)
 """
+import os as _os
+_os.environ.setdefault("CBAS_BUILD_DEBUG", "1")      # bring-up entry points: the debug build of the library
 import ctypes as C
 import json
 import os

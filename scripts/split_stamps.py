@@ -1,5 +1,7 @@
 """Block timeline (s_memtime stamps: prologue / K loop / epilogue) of the precision-4 GEMM forms.
 usage: split_stamps.py TILE[,TILE...] [iters [M]]   TILE = 0 planner, 128/160/192/256 rows, -1 = the 128 x 128 8-wave kernel"""
+import os as _os
+_os.environ.setdefault("CBAS_BUILD_DEBUG", "1")      # bring-up entry points: the debug build of the library
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbas_amd import _lib

@@ -8,6 +8,11 @@ import sys
 for _k, _v in (("OMP_WAIT_POLICY", "PASSIVE"), ("GOMP_SPINCOUNT", "0"), ("KMP_BLOCKTIME", "0")):
     os.environ.setdefault(_k, _v)
 
+# The suite loads the DEBUG build of the library (libcbas_mi355x_debug.so = the product + the stage taps, implementation
+# switches and harnesses of include/cbas_mi355x_debug.h that many tests use).  The product build is covered by
+# tests/test_product_library.py, bench.py and __graft_entry__.smoke(), each in its own process.
+os.environ.setdefault("CBAS_BUILD_DEBUG", "1")
+
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

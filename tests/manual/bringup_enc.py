@@ -1,5 +1,7 @@
 """GPU bring-up: stage-by-stage comparison of the HIP encoder with the numpy oracle (tiny ViT),
 then CLS parity on the committed goldens.  Run on the GPU box: python scripts/bringup_enc.py"""
+import os as _os
+_os.environ.setdefault("CBAS_BUILD_DEBUG", "1")      # bring-up entry points: the debug build of the library
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

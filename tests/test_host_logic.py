@@ -56,18 +56,43 @@ def test_head_param_count_and_flops():
     assert abs(hc.flops_per_frame_naive() / 1e9 - 0.0347) < 5e-4
 
 
+def _declared(header_name):
+    header = open(os.path.join(os.path.dirname(B.HERE), "include", header_name)).read()
+    return set(re.findall(r"\b(cbas_[a-z0-9_]+)\s*\(", header)) - {"cbas_enc_config", "cbas_head_config"}
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
 def test_library_exports_every_declared_symbol():
-    """include/cbas_mi355x.h <-> libcbas_mi355x.so <-> the ctypes table, without touching a GPU."""
-    path = B.build_library()
+    """include/cbas_mi355x.h <-> libcbas_mi355x.so <-> the ctypes table, without touching a GPU: the PRODUCT library exports
+    exactly the declared boundary - no bring-up / harness entry point, no C++ internals (csrc/exports.map)."""
+    path = B.build_library(debug=False)
     lib = C.CDLL(path)
-    header = open(os.path.join(os.path.dirname(B.HERE), "include", "cbas_mi355x.h")).read()
-    declared = set(re.findall(r"\b(cbas_[a-z0-9_]+)\s*\(", header))
-    declared -= {"cbas_enc_config", "cbas_head_config"}
+    declared = _declared("cbas_mi355x.h")
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    loaded = _lib.load()
-    assert loaded.cbas_abi_version() == _lib.EXPECTED_ABI
+    exported = _exported(path)
+    assert {e for e in exported if e.startswith("cbas_")} == declared, {e for e in exported if e.startswith("cbas_")} ^ declared
+    assert not [e for e in exported if "debug" in e.lower()], [e for e in exported if "debug" in e.lower()]
+    assert not [e for e in exported if e.startswith("_Z")], "C++ internals exported"
+    assert lib.cbas_abi_version() == _lib.EXPECTED_ABI
+
+
+def test_debug_library_is_a_superset_with_the_debug_header():
+    """libcbas_mi355x_debug.so = the product boundary + include/cbas_mi355x_debug.h (what the GPU suite loads)."""
+    path = B.build_library(debug=True)
+    lib = C.CDLL(path)
+    product, debug = _declared("cbas_mi355x.h"), _declared("cbas_mi355x_debug.h")
+    assert debug == set(_lib.DEBUG_SIGNATURES), debug ^ set(_lib.DEBUG_SIGNATURES)
+    assert not (product & debug)
+    assert {e for e in _exported(path) if e.startswith("cbas_")} == product | debug
+    assert lib.cbas_debug_build() == 1 and lib.cbas_abi_version() == _lib.EXPECTED_ABI
+    assert all("debug" in d for d in debug), [d for d in debug if "debug" not in d]
 
 
 def test_weight_counts_agree_between_host_and_library():
