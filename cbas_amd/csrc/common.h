@@ -25,14 +25,24 @@ static __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// BRANCH-FREE elementary functions.  The device library's erff / tanhf choose between two formulas with a divergent branch
-// (s_and_saveexec ... s_or exec).  Round 4 found the head's expand kernel returning wrong values in lanes 48-63 of a wave -
-// the last of the four passes of a wave64 VALU instruction - when waves of ANOTHER kernel on the same CU keep the matrix
-// pipe busy (precision 4's attention kernel; a register-only v_mfma_f32_32x32x16_f16 loop in another process): one wrong
-// LayerNorm row in ~15 % of its runs beside the MFMA loop.  Branch-free erf alone: 0.3 %; with the kernel's LDS read-back
-// of its own earlier writes replaced by registers as well: 0 of 10 170 beside the attention kernel, 0 of 381 beside the loop
-// (scripts/head_beside_encoder.py).  Whether the hardware or the generated code is at fault was not
-// established; inference kernels - which run beside other work - use these forms.
+// ROUND 4's CO-RESIDENCY CORRUPTION, ROOT-CAUSED IN ROUND 5 (scripts/expand_rootcause.py;
+// profiles/r05_expand_rootcause.json).  The head's expand kernel returned wrong values in lanes 48-63 of a wave when waves of
+// ANOTHER kernel on the same CU kept the matrix pipe busy with 32x32x16 MFMAs.  Nine single-edit variants of that kernel's
+// assembly, ~78 000 launches each beside the same neighbour, every wrong row captured: the wrong value was always
+// (a - b) - b where (a - b) - (b - c) was due - the LOW half of
+//     v_pk_add_f32 v[8:9], v[10:11], v[8:9] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]        ; {b - c, a - b}
+// computed as b - 0 in the instruction's last 16-lane pass.  Independent of what surrounds it (8 wait states before or after,
+// fresh destination pair, operands from registers instead of LDS, branch-free code around it: still wrong; the same
+// subtraction as scalar v_sub_f32 or as a v_pk_add_f32 WITHOUT cross-half operand selection: 0 of 320 000 launches against
+// 24 of 470 000).  So one instruction FORM is banned from the library - a packed-fp32 op whose low result half reads the high
+// half of a source pair (op_sel with a 1) - and cbas_amd/asmcheck.py fails the build if the compiler emits one anywhere.
+// keep_scalar / add_np below are the source-level way out: an empty asm that pins one of the two scalar results the compiler
+// would have paired.  (Round 4's empirical fix - branch-free erf / tanh, registers instead of an LDS read-back - worked
+// because it changed which operations the vectoriser could pair; the branch-free forms stay: they are also faster.)
+static __device__ __forceinline__ float keep_scalar(float r) { asm("" : "+v"(r)); return r; }
+static __device__ __forceinline__ float add_np(float a, float b) { return keep_scalar(a + b); }
+
+// BRANCH-FREE elementary functions (r4; kept for their speed and because divergent library forms invite the pairing above).
 //   erf: two minimax polynomials (|z| <= 0.9277: z + z P(z^2); beyond: 1 - exp(Q(|z|)), copysign; after N. Juffa's erff),
 //        both evaluated, one selected by v_cndmask; 1.5 ulp against erf in double over [-9, 9] (libm erff: 1.3 ulp)
 static __device__ __forceinline__ float erf_bf(float a) {

@@ -343,7 +343,9 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, int row_
                 f32x4 v[4];
                 if (LN) {
                     const f32x2 st = ln_red[i * 16 + li];                  // (mean, rstd) of row row_base + i*16 + li
-                    const float mu = st[0], rs = st[1];
+                    // own registers for both: broadcasting rs from the HIGH register of the loaded pair is the banned
+                    // packed form (v_pk_fma_f32 ... op_sel:[0,1,0]; common.h)
+                    const float mu = keep_scalar(st[0]), rs = keep_scalar(st[1]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = __builtin_elementwise_fma(acc[i][j] - lnc[j] * mu, f32x4{rs, rs, rs, rs}, bv[j]);
                 } else {

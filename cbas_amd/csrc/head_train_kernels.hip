@@ -33,7 +33,10 @@ __device__ __forceinline__ float drop_scale(unsigned long long key, unsigned lon
     return (unsigned)(mix64(key + idx) >> 40) >= thr ? scale : 0.f;
 }
 
-// training runs alone on the device: it keeps the device library's erff (common.h explains why inference does not)
+// Training shares the device with the encoder and the classifier in CBAS (backend/workthreads.py:1256-1267).  It keeps the
+// device library's erff / tanhf (the reference fixtures' tolerances were set with them): round 5 showed that the wrong values
+// of round 4 came from one packed-fp32 instruction form, not from divergent code (common.h) - this file is compiled with
+// -packed-fp32-ops (build.py), asmcheck bans the form everywhere, tests/test_gpu_round4.py runs training beside the encoder.
 __device__ __forceinline__ float gelu_erf_lib(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // d/dx gelu_erf(x) = Phi(x) + x phi(x)

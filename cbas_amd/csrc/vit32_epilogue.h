@@ -22,6 +22,9 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 // four consecutive columns c .. c+3 (c % 4 == 0) of a row that starts at `row` (float-sized slots): hi and lo halves
+// NP: keep the four low-half subtractions scalar (the weight packer's instantiation paired them into a v_pk_add_f32 with
+// cross-half operand selection, the form common.h bans)
+template <bool NP = false>
 __device__ __forceinline__ void store_split4(float* row, int c, f32x4 v, float scale) {
     const int kk = c & 31;
     char* tile = reinterpret_cast<char*>(row + (c - kk));                       // the K-tile's 128 bytes
@@ -32,7 +35,7 @@ __device__ __forceinline__ void store_split4(float* row, int c, f32x4 v, float s
         const float x = v[e] * scale;
         const f16 h = (f16)x;
         hi[e] = h;
-        lo[e] = (f16)(x - (float)h);
+        lo[e] = (f16)(NP ? keep_scalar(x - (float)h) : x - (float)h);
     }
     *reinterpret_cast<f16x4v*>(tile + pos * 2) = hi;
     *reinterpret_cast<f16x4v*>(tile + 64 + pos * 2) = lo;

@@ -442,7 +442,7 @@ __global__ void pack_split_weight_kernel(const float* __restrict__ w, float* __r
     if (i >= N * per_row) return;
     const int64_t row = i / per_row;
     const int c = (int)(i - row * per_row) * 4;
-    store_split4(out + row * K, c, *reinterpret_cast<const f32x4*>(w + row * K + c), scale);
+    store_split4<true>(out + row * K, c, *reinterpret_cast<const f32x4*>(w + row * K + c), scale);
 }
 
 // one wave per row, two-pass statistics in registers

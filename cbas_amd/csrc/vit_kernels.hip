@@ -718,7 +718,8 @@ __global__ __launch_bounds__(512, KT <= 4 ? 6 : 2) void attention_stream2_kernel
                     e0[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp][r], 1.4426950408889634f, -m2));
                     e1[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * grp + 1][r], 1.4426950408889634f, -m2));
                 }
-                if (!RS) bs += ((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e1[0] + e1[1]) + (e1[2] + e1[3]));
+                // add_np: the same sums in the same order, not paired into v_pk_add_f32 with cross-half selection (common.h)
+                if (!RS) bs += add_np(add_np(add_np(e0[0], e0[1]), add_np(e0[2], e0[3])), add_np(add_np(e1[0], e1[1]), add_np(e1[2], e1[3])));
                 pf[grp] = f16x8{(f16)e0[0], (f16)e0[1], (f16)e0[2], (f16)e0[3], (f16)e1[0], (f16)e1[1], (f16)e1[2], (f16)e1[3]};
             }
             if (RS) ol = ol * alpha;

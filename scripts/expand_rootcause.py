@@ -25,6 +25,8 @@ s_waitcnt lgkmcnt(0); v_pk_add_f32 {b - c, a - b}; s_nop 0; v_sub_f32; ...; dive
                 moved into a fresh pair first, `v_pk_add_f32 v[8:9], v[10:11], v[18:19] neg_lo neg_hi` (the form the current
                 library kernel compiles to)
   pk_nooverlap  asm: the cross-half selection kept, result into a fresh pair (v[18:19]) instead of over src1
+  pk_bcast      asm: the MIRROR form: {a - b, c - b} with b broadcast from the low register of its pair (op_sel_hi:[1,0]), then
+                (a - b) + (c - b): the scalar-broadcast form the compiler uses throughout the GEMM epilogues (asmcheck R2)
 
 Amplification (cbas_head_debug_expand_repeat): every pass launches the probe kernel R times and a device-side kernel compares
 each launch's rows with a reference taken on the idle device, capturing the differing rows: ~60 x the launches per second of
@@ -89,6 +91,11 @@ def build():
                                             "\tv_sub_f32_e32 v18, v9, v8\n")
     variants["pk_nooverlap"] = _edit(base, seq, "\ts_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 v[18:19], v[10:11], v[8:9] op_sel:[0,1] op_sel_hi:[1,0] "
                                                 "neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\tv_sub_f32_e32 v18, v19, v18\n")
+    # the mirror form (asmcheck R2): HIGH halves... {a - b, c - b} with b broadcast from the LOW register of its pair
+    # (op_sel_hi:[1,0]); (a - b) + (c - b) is bit for bit (a - b) - (b - c)
+    variants["pk_bcast"] = _edit(base, seq, "\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v18, v11\n\tv_mov_b32_e32 v19, v9\n"
+                                            "\tv_pk_add_f32 v[18:19], v[18:19], v[8:9] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n"
+                                            "\tv_add_f32_e32 v18, v18, v19\n")
     # v18 / v19 are dead at the edited point: v18 is written by this very sequence, v19 only later (a temporary inside erff)
     return {k: _hsaco(k, v) for k, v in variants.items()}
 
@@ -172,10 +179,11 @@ def run(seconds: float, out_path, repeat: int = 64):
     import numpy as np, torch
     from cbas_amd import config as Cfg, weights as W, _lib
     from cbas_amd.head import ClassifierLSTMDeltas
-    names = ("r4", "nopk", "erfbf", "nop_after_pk", "scalar_subs", "nop_before_pk", "wait_early", "pk_plain", "pk_nooverlap")
+    names = tuple(os.environ.get("EXPAND_VARIANTS", "r4,nopk,erfbf,nop_after_pk,scalar_subs,nop_before_pk,wait_early,pk_plain,pk_nooverlap,pk_bcast").split(","))
     paths = {k: os.path.join(BIN, f"expand_r4_{k}.hsaco") for k in names}
     if not all(os.path.exists(p) for p in paths.values()):
-        paths = build()
+        built = build()
+        paths = {k: built[k] for k in names}
     lib = _lib.load()
     hc = Cfg.HeadConfig()
     sd = W.synth_head_weights(hc, 4321)
@@ -202,7 +210,7 @@ def run(seconds: float, out_path, repeat: int = 64):
     dev = torch.cuda.current_device()
     results = {"seconds_per_variant": seconds, "launches_per_pass": repeat, "windows_per_launch": n,
                "neighbour": "cbas_debug_mfma_neighbor(20000) on the default stream", "variants": {}}
-    for name in ["library"] + list(paths) + ["r4_again"]:
+    for name in ["library"] + list(paths) + (["r4_again"] if "r4" in paths else []):
         key = "r4" if name == "r4_again" else name
         if key == "library":
             _lib.check(lib.cbas_head_debug_expand_module(head._h, None, None), "expand_module")

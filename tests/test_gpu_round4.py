@@ -390,6 +390,24 @@ def test_head_beside_the_encoder_is_bit_stable(precision):
         assert st["head_runs_differing"] == 0, st
 
 
+def test_training_beside_the_encoder_is_bit_stable():
+    """CBAS starts TrainingThread, EncodeThread and ClassificationThread together on one device
+    (backend/workthreads.py:1256-1267): a 40-step training run on its own stream beside precision-4 encoder passes, beside
+    default-precision passes and beside the dense 32x32x16 MFMA loop must produce the losses and the trained weights of the
+    idle-device run, bit for bit (scripts/train_beside_encoder.py).  The training kernels are compiled without packed-fp32
+    instructions (build.py) and asmcheck bans the instruction form round 5 identified from every kernel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "train_beside_encoder", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "train_beside_encoder.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(4.0)
+    print(res)
+    for nb in res:
+        assert nb["runs"] >= 3, nb
+        assert nb["runs_differing"] == 0, nb
+
+
 @pytest.mark.parametrize("precision", [0, 4])
 def test_pipelined_clips_write_the_bytes_of_clips_run_alone(tmp_path, precision):
     """A short form of scripts/soak_files.py (the test that found round 4's head / neighbour interference) at the real

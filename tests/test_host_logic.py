@@ -342,3 +342,31 @@ def test_checkpoint_loader_reads_bf16_and_sharded_saves(tmp_path):
     _, got = W.load_encoder_checkpoint(str(pre))
     assert all(np.array_equal(got[k], ref[k]) for k in ref)
 
+
+
+def test_asmcheck_bans_the_packed_form_round5_identified():
+    """cbas_amd/asmcheck.py: the rule on a hand-written disassembly, then on the device code of every kernel of the product."""
+    from cbas_amd import asmcheck as A
+    text = """
+0000000000001c00 <kern_a>:
+	v_pk_add_f32 v[8:9], v[10:11], v[8:9] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]// 000000001C00: D3B24008 5A021114
+	v_pk_add_f32 v[4:5], v[6:7], v[4:5] neg_lo:[0,1] neg_hi:[0,1]// 000000001C08: D3B24004 1A020906
+	v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]        // 000000001C10: D3B10000 08020902
+	v_pk_fma_f32 v[0:1], v[2:3], s[4:5], v[6:7] op_sel_hi:[1,0,1]// 000000001C18: D3B00000 0C180902
+	v_sub_f32_e32 v18, v9, v8                                  // 000000001C20: 04241109
+0000000000001d00 <kern_b>:
+	v_pk_fma_f32 v[36:37], v[36:37], v[0:1], v[2:3] op_sel:[0,1,0]// 000000001D00: D3B04024 1C0A0124
+"""
+    ks = A.parse_disassembly(text)
+    assert set(ks) == {"kern_a", "kern_b"} and len(ks["kern_a"]) == 5
+    fa, fb = A.check_kernel(ks["kern_a"]), A.check_kernel(ks["kern_b"])
+    assert [f["rule"] for f in fa] == ["R1", "R2"], fa            # the scalar-pair broadcast (s[4:5]) is not a VGPR pair
+    assert [f["rule"] for f in fb] == ["R1"], fb
+    B.build_library(debug=False)
+    rep = A.check_library(enforce=False)
+    assert rep["kernels"] > 150 and rep["packed_f32_ops"] > 10000
+    assert rep["R1"] == [], rep["R1"][:5]
+    # the head's files are compiled without packed fp32 altogether
+    for obj in ("head_kernels.o", "head_train_kernels.o"):
+        ks = A.disassemble_object(os.path.join(B.HERE, "build", obj))
+        assert ks and not [mn for insns in ks.values() for mn, _, _ in insns if mn.startswith("v_pk_") and mn.endswith("_f32")], obj
