@@ -778,7 +778,9 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         w8p = h->w8; s8p = h->w8_sc;
     }
     CREATE_TRY(hipMalloc(&h->qkv_bias_all, (int64_t)h->L * 3 * D * sizeof(float)));
-    CREATE_TRY(hipMemset(h->qkv_bias_all, 0, (int64_t)h->L * 3 * D * sizeof(float)));
+    // on the stream the packing kernels and copies below run on: a null-stream hipMemset may still be in flight when work on a
+    // NON-BLOCKING stream (every stream of this library) touches the buffer - found by running training beside the encoder (r5)
+    CREATE_TRY(hipMemsetAsync(h->qkv_bias_all, 0, (int64_t)h->L * 3 * D * sizeof(float), h->compute));
 
     // LayerNorm fold: folded copies of the q|k|v and up_proj weights (+ column sums and biases), fp16 path only
     h->fold_ok = c.precision == 0 && D % 256 == 0 && D <= 1024 && F % 256 == 0;

@@ -447,6 +447,7 @@ extern "C" int cbas_head_debug_expand_repeat(cbas_head* h, int mode, int repeat)
     if (!h->dbg_counts) {
         HIP_TRY(hipMalloc(&h->dbg_counts, (4 + 1024) * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(h->dbg_counts, 0, (4 + 1024) * sizeof(unsigned long long)));
+        HIP_TRY(hipDeviceSynchronize());             // a null-stream fill may still be in flight: the counters are used on other streams
         h->cap_rows = 512;
         HIP_TRY(hipMalloc(&h->cap, (size_t)h->cap_rows * (2 + h->d.Bn) * sizeof(float)));
     }
@@ -464,7 +465,10 @@ extern "C" int cbas_head_debug_expand_stats(cbas_head* h, uint64_t* counts4, flo
     int n = (int)(counts4[3] < (uint64_t)h->cap_rows ? counts4[3] : (uint64_t)h->cap_rows);
     if (n > max_rows) n = max_rows;
     if (rows_out && n > 0) HIP_TRY(hipMemcpy(rows_out, h->cap, (size_t)n * (2 + h->d.Bn) * sizeof(float), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(h->dbg_counts, 0, (4 + 1024) * sizeof(unsigned long long)));
+    if (reset) {
+        HIP_TRY(hipMemset(h->dbg_counts, 0, (4 + 1024) * sizeof(unsigned long long)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     return CBAS_OK;
 }
 #endif

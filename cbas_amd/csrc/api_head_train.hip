@@ -250,6 +250,12 @@ extern "C" int cbas_head_train_create(const cbas_head_config* cfg, const cbas_tr
         if (8 * h * (L0 > H2 ? L0 : H2) > mx) mx = 8 * h * (L0 > H2 ? L0 : H2);
         TRY_HIP(dalloc(&t->skbuf, 16 * mx));
     }
+    // dalloc zero-fills with hipMemset on the NULL stream, which may return before the fill has run, and the training step is
+    // queued on the caller's stream - in CBAS a torch stream, NON-BLOCKING, hence not ordered after the null stream: beside a
+    // busy encoder the fills of G / M / V landed after the first steps had written them (r5: 114 of 125 forty-step runs
+    // beside encoder passes ended with other weights than the idle-device run; scripts/train_beside_encoder.py).  The handle
+    // is only handed out once every fill has completed.
+    TRY_HIP(hipStreamSynchronize(nullptr));
 #undef TRY_HIP
     *out = t;
     return CBAS_OK;

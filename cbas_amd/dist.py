@@ -207,13 +207,106 @@ _ef_calls = 0
 _ST_OK, _ST_EMPTY, _ST_FAILED = 0, 1, 2
 
 
-def _wait_done(work) -> None:
+class _PeerLost(RuntimeError):
+    """The other side of a transfer will not complete it (its rank has gone silent, or rank 0 gave the gather up)."""
+
+
+def _wait_done(work, give_up=None) -> None:
     """Host-side completion of a transfer.  ``Work.wait()`` on RCCL only makes the current torch stream wait; the buffers
-    these transfers read are rewritten by kernels on the library's own streams, so the host has to see them finished."""
+    these transfers read are rewritten by kernels on the library's own streams, so the host has to see them finished.
+    ``give_up()`` is polled about four times a second while the transfer is outstanding: when it returns a reason the wait
+    is abandoned with ``_PeerLost`` (the transfer itself cannot be cancelled; the caller stops using the communicator)."""
     import time
-    work.wait()
-    while not work.is_completed():
+    if give_up is None:
+        work.wait()
+        while not work.is_completed():
+            time.sleep(0.0002)
+        return
+    if dist.get_backend() != "nccl":
+        # gloo: is_completed() only turns true inside wait(), and wait() blocks the host - so the wait runs on a helper thread
+        # (left behind, blocked, if the transfer is given up: the job is ending then)
+        import threading
+        done = threading.Event()
+        err: list = []
+
+        def waiter():
+            try:
+                work.wait()
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+            done.set()
+        threading.Thread(target=waiter, name="cbas-p2p-wait", daemon=True).start()
+        while not done.wait(0.25):
+            why = give_up()
+            if why:
+                raise _PeerLost(why)
+        if err:
+            raise err[0]
+        return
+    n = 0
+    while not work.is_completed():         # RCCL: wait() would only make the current stream wait; poll, about 4 give_up()s a second
         time.sleep(0.0002)
+        n += 1
+        if n % 1250 == 0:
+            why = give_up()
+            if why:
+                raise _PeerLost(why)
+    work.wait()                            # completed: orders the current stream after it, returns at once
+
+
+class _DictStore:
+    """The four store calls encode_files uses, on a dict: the world of one process has no process group store."""
+
+    def __init__(self):
+        import threading
+        self._d, self._lock = {}, threading.Lock()
+
+    def set(self, k, v):
+        with self._lock:
+            self._d[k] = v if isinstance(v, bytes) else str(v).encode()
+
+    def get(self, k):
+        with self._lock:
+            return self._d[k]
+
+    def add(self, k, n):
+        with self._lock:
+            v = int(self._d.get(k, b"0")) + int(n)
+            self._d[k] = str(v).encode()
+            return v
+
+    def check(self, keys):
+        with self._lock:
+            return all(k in self._d for k in keys)
+
+
+class _Liveness:
+    """Rank 0's view of which ranks can still publish or complete a transfer.  A rank has LEFT (it sets ``left<r>`` after its
+    last ticket) or has gone SILENT: the value of its heartbeat key has not CHANGED for ``dead_after`` seconds of this
+    process's own monotonic clock - no wall-clock time of another host is compared with ours."""
+
+    def __init__(self, st, prefix: str, world: int, dead_after: float):
+        import time
+        self._st, self._prefix, self._dead_after = st, prefix, dead_after
+        now = time.monotonic()
+        self._last = {r: (None, now) for r in range(world)}
+        self._left: set = set()
+
+    def left(self, r: int) -> bool:
+        if r not in self._left and self._st.check([f"{self._prefix}left{r}"]):
+            self._left.add(r)
+        return r in self._left
+
+    def silent(self, r: int) -> bool:
+        import time
+        key = f"{self._prefix}hb{r}"
+        now = time.monotonic()
+        val = self._st.get(key) if self._st.check([key]) else None
+        seen, since = self._last[r]
+        if val != seen:
+            self._last[r] = (val, now)
+            return False
+        return now - since > self._dead_after
 
 
 def _p2p(op, tensor: torch.Tensor, peer: int):
@@ -270,6 +363,8 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     if world > 1:
         barrier()          # every rank is here; on RCCL this also creates the communicator the transfers below share
     queue_ = _ClipQueue(len(paths), store, prefix)
+    tstore = store if store is not None else _DictStore()  # tickets, counters, abort flag (a dict in a world of one process)
+    abort_key = prefix + "abort"
     dead_after = float(os.environ.get("CBAS_GATHER_DEAD_AFTER", "120"))
     hb_stop = threading.Event()
     hb = None
@@ -277,9 +372,11 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
         hb_store = store.clone() if hasattr(store, "clone") else store
 
         def heartbeat():
+            beat = 0
             while True:
+                beat += 1
                 try:
-                    hb_store.set(f"{prefix}hb{rank}", repr(time.time()))
+                    hb_store.set(f"{prefix}hb{rank}", str(beat))       # any CHANGING value: rank 0 times the changes on its own clock
                 except Exception:  # noqa: BLE001 - the store is going away with the job
                     return
                 if hb_stop.wait(1.0):
@@ -315,51 +412,87 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 rows = torch.empty((n, D), dtype=torch.float16, device=dev)
                 probs = torch.empty((n, Cn), dtype=torch.float32, device=dev) if (Cn and t["probs"]) else None
                 if n:
+                    # a sender that dies after publishing its ticket never completes this transfer: give up when it has left
+                    # without it or gone silent (the receive cannot be cancelled: the caller abandons the gather)
+                    def lost(src=src):
+                        return (f"rank {src} went away with the rows of {paths[clip]} announced but not sent"
+                                if live is not None and (live.silent(src)) else None)
                     for w in _p2p(dist.irecv, rows, src):
-                        _wait_done(w)
+                        _wait_done(w, lost)
                     if probs is not None:
                         for w in _p2p(dist.irecv, probs, src):
-                            _wait_done(w)
+                            _wait_done(w, lost)
                 rows = rows.cpu().numpy()
                 probs = probs.cpu().numpy() if probs is not None else None
             writer.submit(clip, rows, probs)
 
         def receive():
+            """Tickets are per-rank sequences: rank r's j-th finished clip is `t<r>_<j>`, announced by incrementing `cnt<r>`
+            AFTER the ticket is in the store - there is no shared sequence number a dying rank could leave a hole in, and
+            the order of a rank's tickets is the order of its sends (what point-to-point matching needs)."""
             try:
                 if nccl:
                     torch.cuda.set_device(dev)
                 # its own client connection: a blocking store call here must not hold up the encode loop's counter
-                st = store.clone() if store is not None and hasattr(store, "clone") else store
-                for k in range(len(paths)):                # exactly one ticket per clip
-                    key = f"{prefix}t{k}"
-                    waited = 0
-                    while not (key in tickets if st is None else st.check([key])):
-                        if stop.is_set():
-                            return
-                        time.sleep(0.001)
-                        waited += 1
-                        # Liveness (about once a second): a rank that has LEFT has published every ticket it was going to
-                        # (its `finally` marks the clips it took but did not deliver as failed first); a rank whose
-                        # heartbeat has stopped for `dead_after` seconds will publish nothing more.  When every rank is one
-                        # or the other, the tickets still missing will never come: the clips without one stay "failed"
-                        # in the records and the receiver returns instead of blocking rank 0 for ever.
-                        if st is not None and waited % 1000 == 0 and not st.check([key]):
-                            now = time.time()
-                            gone = 0
-                            for r in range(world):
-                                if st.check([f"{prefix}left{r}"]):
-                                    gone += 1
-                                elif st.check([f"{prefix}hb{r}"]) and now - float(st.get(f"{prefix}hb{r}").decode()) > dead_after:
-                                    print(f"cbas_amd.encode_files: rank {r} has not been heard from for {dead_after:.0f} s; "
-                                          "its outstanding clips are marked failed")
-                                    gone += 1
-                            if gone == world and not st.check([key]):
-                                return
-                    take(tickets.pop(key) if st is None else json.loads(st.get(key).decode()))
+                st = store.clone() if store is not None and hasattr(store, "clone") else tstore
+                nonlocal live
+                live = _Liveness(st, prefix, world, dead_after) if store is not None else None
+                nxt = [0] * world
+                done_ranks: set = set()
+                got, idle, gather_over = 0, 0, False
+                while got < len(paths) and len(done_ranks) < world:       # exactly one ticket per clip
+                    progressed = False
+                    for r in range(world):
+                        if r in done_ranks:
+                            continue
+                        # `left<r>` is set after rank r's last ticket: seen BEFORE the counter is read, the counter is final
+                        is_left = live is not None and idle % 50 == 0 and live.left(r)
+                        avail = int(st.add(f"{prefix}cnt{r}", 0))
+                        while nxt[r] < avail:
+                            t = json.loads(st.get(f"{prefix}t{r}_{nxt[r]}").decode())
+                            nxt[r] += 1
+                            got += 1
+                            progressed = True
+                            if gather_over and t["rank"] != 0 and t["status"] == _ST_OK and not t.get("local"):
+                                records[t["clip"]].update(rank=t["rank"], status="failed")      # rows that will not be received
+                                continue
+                            try:
+                                take(t)
+                            except _PeerLost as e:
+                                # the announced rows will never arrive and the receive cannot be cancelled (on RCCL every later
+                                # receive would queue behind it): this clip and every clip of another rank not received yet are
+                                # "failed", senders still waiting are told to stop; rank 0's own clips are still written
+                                print(f"cbas_amd.encode_files: {e}; no further rows are gathered")
+                                records[t["clip"]]["status"] = "failed"
+                                tstore.set(abort_key, "1")
+                                gather_over = True
+                        if is_left:
+                            done_ranks.add(r)
+                    if progressed:
+                        idle = 0
+                        continue
+                    if stop.is_set():
+                        return
+                    time.sleep(0.001)
+                    idle += 1
+                    # Liveness (about once a second): a rank whose heartbeat has not changed for `dead_after` seconds will
+                    # publish nothing more; its outstanding clips stay "failed" in the records and the receiver goes on with
+                    # the others instead of blocking rank 0 for ever.
+                    if live is not None and idle % 1000 == 0:
+                        for r in range(world):
+                            if r not in done_ranks and not live.left(r) and live.silent(r):
+                                print(f"cbas_amd.encode_files: rank {r} has not been heard from for {dead_after:.0f} s; "
+                                      "its outstanding clips are marked failed")
+                                done_ranks.add(r)
             except BaseException as e:  # noqa: BLE001 - re-raised by the caller after the join
                 recv_err.append(e)
+                # the gather is over: senders still waiting for a receive that will never be posted must stop waiting
+                try:
+                    tstore.set(abort_key, "1")
+                except Exception:  # noqa: BLE001
+                    pass
 
-        tickets: dict = {}                                 # world == 1: the store is a dict
+        live = None
         stop = threading.Event()
         receiver = threading.Thread(target=receive, name="cbas-gather", daemon=True)
         receiver.start()
@@ -370,12 +503,12 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     def publish(clip: int, status: int, n: int, has_probs: bool):
         published.add(clip)
         t = {"rank": rank, "clip": clip, "status": status, "n": int(n), "probs": bool(has_probs), "local": lw}
-        if store is None:
-            tickets[f"{prefix}t{clip_seq[0]}"] = t
-            clip_seq[0] += 1
-        else:
-            k = int(store.add(prefix + "done", 1)) - 1
-            store.set(f"{prefix}t{k}", json.dumps(t))
+        tstore.set(f"{prefix}t{rank}_{clip_seq[0]}", json.dumps(t))       # the ticket first ...
+        clip_seq[0] += 1
+        tstore.add(f"{prefix}cnt{rank}", 1)                                # ... then its announcement: no holes
+
+    def gather_given_up():
+        return "rank 0 gave the gather up" if tstore.check([abort_key]) else None
 
     clip_seq = [0]
     finished = False
@@ -400,17 +533,17 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             writer.submit(clip, rows, probs)
             publish(clip, _ST_OK, n, has_probs)
             return
-        publish(clip, _ST_OK, n, has_probs)
-        if n:
+        if n:                                              # the sends are posted BEFORE the ticket that announces them
             rows = res.rows if nccl else torch.from_numpy(res.rows) if not res.on_device else res.rows.cpu()
             work = _p2p(dist.isend, rows.contiguous(), 0)
             probs = None
             if has_probs:
                 probs = res.probs if nccl else torch.from_numpy(res.probs) if not res.on_device else res.probs.cpu()
                 work += _p2p(dist.isend, probs.contiguous(), 0)
-            res.pending.extend(lambda w=w: _wait_done(w) for w in work)     # before the session is reused
+            res.pending.extend(lambda w=w: _wait_done(w, gather_given_up) for w in work)     # before the session is reused
             sends.append((work, rows, probs))
             sends[:] = [s_ for s_ in sends if not all(w.is_completed() for w in s_[0])]
+        publish(clip, _ST_OK, n, has_probs)
 
     # Clips are pipelined back to back where the results go to HOST memory (rank 0, gloo, one process): clip i+1 is pushed
     # before clip i's tail - its last batches, the tail classification, the copy-out - is waited for, so the GPU never idles
@@ -481,7 +614,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 publish(pc, _ST_FAILED, 0, False)
         for work, _r, _p in sends:
             for w in work:
-                _wait_done(w)
+                _wait_done(w, gather_given_up)
         finished = True
     finally:
         if ahead is not None:                              # an error is on its way up with a clip opened ahead
@@ -522,15 +655,16 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             if lw:
                 # the other ranks' outcomes: each publishes `written<r>` before `left<r>`; a rank that is gone without it
                 # leaves its clips "failed"
+                lv = _Liveness(store, prefix, world, dead_after)
                 for r in range(1, world):
-                    t_wait = 0.0
+                    polls = 0
                     while not store.check([f"{prefix}written{r}"]):
-                        if store.check([f"{prefix}left{r}"]) and not store.check([f"{prefix}written{r}"]):
+                        if lv.left(r) and not store.check([f"{prefix}written{r}"]):
                             break
-                        if store.check([f"{prefix}hb{r}"]) and time.time() - float(store.get(f"{prefix}hb{r}").decode()) > dead_after:
+                        polls += 1
+                        if polls % 250 == 0 and lv.silent(r):      # its heartbeat value has not changed for dead_after s of OUR clock
                             break
                         time.sleep(0.002)
-                        t_wait += 0.002
                     got = json.loads(store.get(f"{prefix}written{r}").decode()) if store.check([f"{prefix}written{r}"]) else {}
                     for c, rec in enumerate(records):
                         if rec["rank"] == r and rec["status"] == "ok":

@@ -58,16 +58,21 @@ def main(argv=None) -> int:
                          "to rank 0: no write queue on rank 0 when there is about one video per GPU")
     ap.add_argument("--max-batch", type=int, default=128)
     ap.add_argument("--max-frame", type=int, nargs=2, default=(256, 256))
-    ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2, 3, 4),
-                    help="0 fp16 (meets the 1e-3 CLS contract), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode "
-                         "(needs --experimental-fp8), 3 fp32 end to end - the reference's CPU arithmetic: the reference's "
-                         "own argmax labels, at ~1/7 of the default frame rate; 4 the same with the GEMM products as three-term fp16 "
-                         "splits: as exact, ~1/3.5 of the default frame rate")
+    ap.add_argument("--precision", type=int, default=None, choices=(0, 1, 2, 3, 4),
+                    help="default: CBAS_PRECISION from the environment, else 4 = fp32 storage / attention / LayerNorm with the GEMM "
+                         "products as three-term fp16 splits: rows ~1e-6 from the reference's fp32 CPU path and every argmax "
+                         "label the reference's.  0 = the explicit fast mode: fp16 operands (the reference's own GPU behaviour "
+                         "under autocast), 2.2x the frame rate, rows within the 1e-3 contract, <= 1 %% of near-tie labels differ "
+                         "from the CPU path.  1 fp16 hi+lo weights; 2 MX-fp8 throughput mode (needs --experimental-fp8); 3 fp32 "
+                         "end to end on the fp32 matrix pipe (the literal restatement, 1/3 of mode 4's rate)")
     ap.add_argument("--experimental-fp8", action="store_true",
                     help="allow --precision 2: rows are ~6e-2 from the fp32 reference, NOT interchangeable with fp16 rows; "
                          "the files are stamped '<encoder>#mx-fp8' + attr encoder_precision so that CBAS and this tool "
                          "treat them as made by a different encoder")
     args = ap.parse_args(argv)
+    if args.precision is None:
+        from .encoder import DEFAULT_PRECISION
+        args.precision = int(os.environ.get("CBAS_PRECISION", str(DEFAULT_PRECISION)))
     if args.precision == 2 and not args.experimental_fp8:
         ap.error("--precision 2 writes MX-fp8 rows that heads trained on fp16 embeddings must not consume; "
                  "pass --experimental-fp8 to write them (stamped as such)")

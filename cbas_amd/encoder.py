@@ -56,6 +56,13 @@ def _device_index(device: torch.device) -> int:
     return device.index if device.index is not None else torch.cuda.current_device()
 
 
+# What an encoder built the reference's way - DinoEncoder(model_identifier, device), integration.install(),
+# `python -m cbas_amd.encode_files` - computes in: 4 = fp32 storage / attention / LayerNorm with the GEMM products as three-term
+# fp16 splits: the mode that meets BOTH halves of the path's contract (CLS within 1e-3 - by three orders of magnitude - and
+# argmax labels identical to the reference CPU path).  The fp16-operand mode (0) is the explicit fast mode.
+DEFAULT_PRECISION = 4
+
+
 class DinoEncoder:
     """MI355X DINOv3 ViT encoder behind the reference's ``DinoEncoder`` interface."""
 
@@ -67,10 +74,13 @@ class DinoEncoder:
         ckpt = find_checkpoint_dir(model_identifier)
         cfg, weights = load_encoder_checkpoint(ckpt)
         if precision is None:
-            # CBAS constructs the encoder as DinoEncoder(model_identifier=..., device=...) (startup_page.py:66-69): the
-            # arithmetic mode of an unmodified checkout is chosen through the environment.  0 = fp16 operands (fastest),
-            # 4 = the label-exact mode (include/cbas_mi355x.h).  MX-fp8 (2) is refused here: its rows need their own heads.
-            precision = int(os.environ.get("CBAS_PRECISION", "0"))
+            # CBAS constructs the encoder as DinoEncoder(model_identifier=..., device=...) (startup_page.py:66-69): an
+            # unmodified checkout gets DEFAULT_PRECISION = 4, the contract-complete mode - CLS rows ~1e-6 from the reference's
+            # fp32 CPU path and EVERY argmax label the reference's (tests/test_gpu_fp32.py strict gates; 10.5k frames/s for
+            # ViT-B/16 on one MI355X).  CBAS_PRECISION=0 opts into the reference's own GPU behaviour - fp16 operands, as under
+            # its torch.autocast (cbas.py:433-434) - 2.2x faster, rows within 1e-3, <= 1 % of near-tie labels differ from the
+            # CPU path.  MX-fp8 (2) is refused here: its rows need their own heads.
+            precision = int(os.environ.get("CBAS_PRECISION", str(DEFAULT_PRECISION)))
             if precision == 2:
                 raise ValueError("CBAS_PRECISION=2 (MX-fp8) is not selectable through the environment: its rows are not "
                                  "interchangeable with the other modes' (pass precision=2 explicitly)")
@@ -129,9 +139,9 @@ class DinoEncoder:
 
     @property
     def precision(self) -> int:
-        """0 fp16 (default), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode, 3 fp32 end to end - the reference's CPU
-        arithmetic, for label-exact runs, 4 the same with the GEMM products as three-term fp16 splits (as exact, twice as
-        fast) (include/cbas_mi355x.h)."""
+        """0 fp16 operands (the explicit fast mode; `from_weights`' default), 1 fp16 hi+lo weights, 2 MX-fp8 throughput mode,
+        3 fp32 end to end - the reference's CPU arithmetic, 4 the same with the GEMM products as three-term fp16 splits (as
+        exact, three times as fast: the DEFAULT of an encoder built the reference's way) (include/cbas_mi355x.h)."""
         return int(self._cfg_c.precision)
 
     # -- nn.Module-like surface used by the reference ------------------------------------------

@@ -4,6 +4,7 @@ equal to the single-process `encode_file` / `infer_file` results.  The encoder a
 product classes' interfaces (there is no CPU path of the real ones); the GPU suite runs the real ones at world 1."""
 import hashlib
 import os
+import time
 import socket
 
 import numpy as np
@@ -466,6 +467,59 @@ def test_a_rank_that_leaves_early_fails_its_clips_and_rank0_returns(tmp_path):
     if got[1][0]:                                                    # rank 1 drew a poisoned clip and left
         assert 1 <= len(failed) <= 3 and all(r["rank"] == 1 for r in failed), failed
     assert len(ok) + len(failed) == 7 and all(os.path.exists(r["cls_file"]) and os.path.exists(r["csv_file"]) for r in ok)
+
+
+def _liveness_worker(rank, world, port, td, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      CBAS_GATHER_DEAD_AFTER="4")
+    cdist.init_from_env("gloo")
+    paths = sorted(p for p in (os.path.join(td, f) for f in os.listdir(td)) if p.endswith(".npy"))
+    if rank == 1 and mode == "announced_not_sent":
+        cdist._p2p = lambda op, tensor, peer: []                     # tickets are published, the rows never leave
+    if rank == 1 and mode == "dies_in_send":
+        def die(op, tensor, peer):                                   # the process is gone before it could announce anything
+            os._exit(0)
+        cdist._p2p = die
+    t0 = time.time()
+    recs = cdist.encode_files(paths, LatencyEncoder(0.0005), head=StubHead(), dataset_name="gold", behaviors=NAMES)
+    q.put((rank, time.time() - t0, recs))
+    if mode == "announced_not_sent":
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["announced_not_sent", "dies_in_send"])
+def test_receiver_does_not_wait_for_ever_for_a_lost_sender(tmp_path, mode):
+    """(a) a rank whose ticket announces rows that never arrive used to leave rank 0's receiver inside its receive
+    for ever; (b) a rank that dies between taking a clip and announcing it must not leave a hole in the ticket order.  Now
+    tickets are per-rank sequences, the receive polls the sender's heartbeat as seen on rank 0's OWN clock, and rank 0
+    returns its records - the lost rank's clips "failed", its own written - within a few `dead_after`s."""
+    td = str(tmp_path)
+    rng = np.random.default_rng(11)
+    for i in range(6):
+        np.save(os.path.join(td, f"clip{i}.npy"), rng.integers(0, 200, (60, 8, 8, 3), dtype=np.uint8))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_liveness_worker, args=(r, 2, port, td, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2 if mode == "announced_not_sent" else 1):
+        rank, dt, recs = q.get(timeout=90)
+        got[rank] = (dt, recs)
+    for p in procs:
+        p.join(30)
+        if p.is_alive():
+            p.terminate()
+    dt, recs = got[0]
+    assert recs is not None and len(recs) == 6 and dt < 60, dt
+    ok = [r for r in recs if r["status"] == "ok"]
+    failed = [r for r in recs if r["status"] == "failed"]
+    assert len(ok) >= 1 and len(failed) >= 1 and len(ok) + len(failed) == 6, recs
+    assert all(r["rank"] == 0 for r in ok)                            # what rank 0 encoded itself is on disk
+    assert all(os.path.exists(r["cls_file"]) and os.path.exists(r["csv_file"]) for r in ok)
+    assert all(r["cls_file"] is None for r in failed)
 
 
 # ---- cfg3 rehearsed at world 8 (VERDICT r3 item 7) ------------------------------------------------------------------------

@@ -295,8 +295,8 @@ def test_fp32_dinov2_with_registers(golden_dir, precision):
         enc.close()
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
-def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, tmp_path, precision):
+@pytest.mark.parametrize("precision", PRECISIONS + ["default"])
+def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, tmp_path, monkeypatch, precision):
     """encode_file / infer_file / encode_infer_file with a precision-3 encoder, against the `_cls.h5` rows the REFERENCE's
     own encode_file wrote for the same 600-frame 'video' (tests/golden/encode_file_b1layer.npz): the fp16 rows are the
     reference's except where a value sits on a rounding boundary (well under 1 % of the elements, one ulp each) - the
@@ -305,7 +305,16 @@ def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, 
     from cbas_amd.encoder import DinoEncoder
     g = load(golden_dir, "encode_file_b1layer")
     cfg = C.ViTConfig(hidden_size=768, intermediate_size=1536, num_hidden_layers=1, num_attention_heads=12, image_size=32)
-    enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(32, 32), precision=precision)
+    if precision == "default":
+        # built the reference's way - DinoEncoder(model_identifier, device), no precision anywhere (startup_page.py:66-69):
+        # the drop-in's default must be the contract-complete mode
+        monkeypatch.delenv("CBAS_PRECISION", raising=False)
+        ck = str(tmp_path / "ck")
+        W.save_encoder_checkpoint(ck, cfg, W.synth_encoder_weights(cfg, 1234))
+        enc = DinoEncoder(ck, device="cuda", max_batch=64, max_frame=(32, 32))
+        assert enc.precision == 4
+    else:
+        enc = DinoEncoder.from_weights(cfg, W.synth_encoder_weights(cfg, 1234), "cuda", max_batch=64, max_frame=(32, 32), precision=precision)
     head = make_head(768)
     try:
         frames = synth.cage_frames(5, 600, 32, 32)

@@ -151,6 +151,29 @@ def test_precision_argument_checks_without_gpu(tmp_path, monkeypatch):
         DinoEncoder(ck, device="cuda")
 
 
+def test_reference_style_construction_defaults_to_the_contract_complete_mode(tmp_path, monkeypatch):
+    """DinoEncoder(model_identifier, device) - how CBAS builds its encoder (startup_page.py:66-69), hence what
+    integration.install() hands an unmodified checkout - and `python -m cbas_amd.encode_files` compute in precision 4 (CLS
+    ~1e-6 from the reference's fp32 CPU rows, every argmax label the reference's) unless CBAS_PRECISION / --precision says
+    otherwise; the fp16-operand mode is the explicit opt-in."""
+    from cbas_amd import encoder as E
+    assert E.DEFAULT_PRECISION == 4
+    ck = str(tmp_path / "ck")
+    W.save_encoder_checkpoint(ck, Cfg.VIT_TINY, W.synth_encoder_weights(Cfg.VIT_TINY, 3))
+    seen = []
+    monkeypatch.setattr(E.DinoEncoder, "_init", lambda self, cfg, w, dev, mb, mf, precision: seen.append(precision))
+    monkeypatch.delenv("CBAS_PRECISION", raising=False)
+    E.DinoEncoder(ck, device="cuda")
+    monkeypatch.setenv("CBAS_PRECISION", "0")
+    E.DinoEncoder(ck, device="cuda")
+    E.DinoEncoder(ck, device="cuda", precision=3)
+    assert seen == [4, 0, 3]
+    # the command-line tool resolves its default the same way
+    import cbas_amd.encode_files as EF
+    src = open(EF.__file__).read()
+    assert 'default=None, choices=(0, 1, 2, 3, 4)' in src and "DEFAULT_PRECISION" in src
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
