@@ -56,6 +56,7 @@ SIGNATURES = {
     "cbas_enc_wait_stream": (c_int, [c_void_p, c_int, c_void_p]),
     "cbas_enc_submit_u8_host_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                             c_void_p, c_void_p, c_void_p]),
+    "cbas_enc_check_finite": (c_int, [c_void_p]),
     "cbas_enc_copy_stream": (c_void_p, [c_void_p]),
     "cbas_enc_get_config": (c_int, [c_void_p, C.POINTER(EncConfig)]),
     "cbas_head_get_config": (c_int, [c_void_p, C.POINTER(HeadConfigC)]),

@@ -79,6 +79,7 @@ struct cbas_enc {
     const float* wpatch32 = nullptr;
     float sc_patch = 1.f;                      // precision 4: scale of the patch weight (see LayerW)
     float* qkv_bias_all = nullptr;
+    unsigned* nonfinite_dev = nullptr;  // frames whose CLS row came out non-finite since the last cbas_enc_check_finite
     float* prefix_dev = nullptr;        // (1+R, D): cls (+ its position embedding for DINOv2) | registers
     float* pos_tab = nullptr;           // DINOv2: (Pmax, D) position embedding interpolated to the current grid
     std::vector<float> pos_host;        // DINOv2: raw (1+G*G, D) table
@@ -495,7 +496,7 @@ int run_blocks_f32(cbas_enc* h, int n, int height, int width, float* cls_f32, f1
         if (stop(7)) return CBAS_OK;
     }
     if (cls_f32 || cls_f16)
-        LAUNCH_TRY(launch_final_norm_cls(h->x, h->norm_w, h->norm_b, cls_f32, cls_f16, n, T, D, eps, st));
+        LAUNCH_TRY(launch_final_norm_cls(h->x, h->norm_w, h->norm_b, cls_f32, cls_f16, n, T, D, eps, st, h->nonfinite_dev));
     return CBAS_OK;
 }
 
@@ -627,7 +628,7 @@ int run_blocks(cbas_enc* h, int n, int height, int width, int patch_k, float in_
     }
     if (cls_f32 || cls_f16)
         LAUNCH_TRY(launch_final_norm_cls(h->x, h->norm_w, h->norm_b, cls_f32, cls_f16, n, T, D,
-                                         h->cfg.layer_norm_eps, st));
+                                         h->cfg.layer_norm_eps, st, h->nonfinite_dev));
     return CBAS_OK;
 }
 
@@ -674,6 +675,7 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
     (void)hipSetDevice(h->device);
     if (h->compute) (void)hipStreamSynchronize(h->compute);
     if (h->copy) (void)hipStreamSynchronize(h->copy);
+    if (h->nonfinite_dev) (void)hipFree(h->nonfinite_dev);
     for (Slot& s : h->slots) {
         if (s.in_host) (void)hipHostFree(s.in_host);
         if (s.out16_host) (void)hipHostFree(s.out16_host);
@@ -777,6 +779,8 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
         CREATE_TRY(hipMalloc(&h->w8_sc, n8 / 32));              // one E8M0 byte per 32 elements
         w8p = h->w8; s8p = h->w8_sc;
     }
+    CREATE_TRY(hipMalloc(&h->nonfinite_dev, sizeof(unsigned)));
+    CREATE_TRY(hipMemsetAsync(h->nonfinite_dev, 0, sizeof(unsigned), h->compute));
     CREATE_TRY(hipMalloc(&h->qkv_bias_all, (int64_t)h->L * 3 * D * sizeof(float)));
     // on the stream the packing kernels and copies below run on: a null-stream hipMemset may still be in flight when work on a
     // NON-BLOCKING stream (every stream of this library) touches the buffer - found by running training beside the encoder (r5)
@@ -1311,6 +1315,24 @@ extern "C" int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream) {
     return CBAS_OK;
 }
 
+// Frames whose CLS row came out NaN / infinite since the last call (the counter is cleared): CBAS_ERANGE when there are any.
+// Meaningful after the batches in question have completed (cbas_enc_wait and the fused session's waits call it themselves).
+extern "C" int cbas_enc_check_finite(cbas_enc* h) {
+    if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned n = 0;
+    HIP_TRY(hipMemcpy(&n, h->nonfinite_dev, sizeof(n), hipMemcpyDeviceToHost));
+    if (!n) return CBAS_OK;
+    const unsigned zero = 0;
+    HIP_TRY(hipMemcpy(h->nonfinite_dev, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    return cbas_fail(CBAS_ERANGE, "%u frame(s) produced a non-finite CLS row: an activation left the range of precision %d%s",
+                     n, h->cfg.precision,
+                     h->cfg.precision == 4 ? " (operands are split into fp16 halves after power-of-two scaling: |GELU output| < 16 376, "
+                                             "|k|, |v| < 16 376, ... - include/cbas_mi355x.h); precision 3 (CBAS_PRECISION=3) computes "
+                                             "the same rows in fp32 without a range limit"
+                                           : h->cfg.precision == 3 ? "" : " (fp16 activations: |value| < 65 504); precisions 3 / 4 keep them in fp32");
+}
+
 extern "C" int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, float* cls_f32_host) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
     if (slot < 0 || slot >= CBAS_ENC_SLOTS) return cbas_fail(CBAS_EINVAL, "slot %d out of range", slot);
@@ -1322,7 +1344,7 @@ extern "C" int cbas_enc_wait(cbas_enc* h, int slot, uint16_t* cls_f16_host, floa
     if (cls_f16_host) memcpy(cls_f16_host, s.out16_host, (int64_t)s.n * h->D * 2);
     if (cls_f32_host) memcpy(cls_f32_host, s.out32_host, (int64_t)s.n * h->D * 4);
     s.busy = false;
-    return CBAS_OK;
+    return cbas_enc_check_finite(h);
 }
 
 extern "C" int cbas_enc_profile(cbas_enc* h, int enable) {

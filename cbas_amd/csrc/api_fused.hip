@@ -270,6 +270,7 @@ int finish_impl(cbas_fused* f, uint16_t* cls_f16_host, float* probs_host, const 
     } else if (mode == 0) {
         HIP_TRY(hipEventSynchronize(f->clip_done));                     // results are complete at return
         f->clip_pending = false;
+        return cbas_enc_check_finite(f->enc);                           // CBAS_ERANGE instead of NaN rows in a file
     }
     return CBAS_OK;
 }
@@ -287,6 +288,10 @@ extern "C" int cbas_fused_finish_async(cbas_fused* f, uint16_t* cls_f16_host, fl
 extern "C" int cbas_fused_wait(cbas_fused* f) {
     if (!f) return cbas_fail(CBAS_EINVAL, "null session");
     HIP_TRY(hipSetDevice(f->device));
-    if (f->clip_pending) { HIP_TRY(hipEventSynchronize(f->clip_done)); f->clip_pending = false; }
+    if (f->clip_pending) {
+        HIP_TRY(hipEventSynchronize(f->clip_done));
+        f->clip_pending = false;
+        return cbas_enc_check_finite(f->enc);
+    }
     return CBAS_OK;
 }

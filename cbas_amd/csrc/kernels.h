@@ -122,8 +122,9 @@ int launch_ln_stats_x16(const float* x, f16* x16, float2* ln_out, int ln_ld, int
 int launch_fold_ln_weight(const float* W, const float* gamma, const float* beta, const float* b, f16* Wf, float* colsum,
                           float* biasf, int N, int K, hipStream_t stream);
 // Final LayerNorm on the CLS row of every frame: x[b*T] -> cls_f32[b][D] / cls_f16[b][D]
+// `nonfinite` (may be NULL): incremented once per frame whose CLS row holds a NaN / infinity
 int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
-                          f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream);
+                          f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream, unsigned* nonfinite = nullptr);
 
 // Multi-head attention over frames: qkv16 [n*T][3D] (q pre-scaled by 1/8, RoPE applied) -> o16 [n*T][D]
 // q_cls != nullptr: only the CLS query of every frame (the last layer: [tf]:540-541 + cbas.py:677 consume row 0

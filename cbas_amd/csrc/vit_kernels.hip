@@ -228,13 +228,28 @@ __global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float* __rest
 template <int NV>
 __global__ __launch_bounds__(256) void final_norm_cls_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ cls_f32,
-                                                             f16* __restrict__ cls_f16, int n, int T, int D, float eps) {
+                                                             f16* __restrict__ cls_f16, int n, int T, int D, float eps,
+                                                             unsigned* __restrict__ nonfinite) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n) return;
     f32x4 y[NV];
     ln_row<NV>(x + (size_t)b * T * D, gamma, beta, D, eps, lane, y);
     const int nvec = D >> 2;
+    // A non-finite value anywhere in the encoder reaches the CLS row (every query attends to every key): one test per
+    // frame here watches the whole forward pass.  The reference's fp32 arithmetic has no range limit; the split-fp16 operands
+    // of precision 4 (|x| scale < 65 504, vit32_epilogue.h) and the fp16 activations of precision 0 do - a violation is
+    // counted and turned into CBAS_ERANGE at the next wait instead of NaN rows in a `_cls.h5`.
+    if (nonfinite) {
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + 64 * k < nvec) {
+                const f32x4 a = __builtin_elementwise_abs(y[k]);
+                bad |= !(a[0] <= 3.0e38f && a[1] <= 3.0e38f && a[2] <= 3.0e38f && a[3] <= 3.0e38f);
+            }
+        if (__ballot(bad) && lane == 0) atomicAdd(nonfinite, 1u);
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int idx = lane + 64 * k;
@@ -924,14 +939,14 @@ int launch_layernorm_f8(const float* x, int64_t ldx, const float* gamma, const f
 }
 
 int launch_final_norm_cls(const float* x, const float* gamma, const float* beta, float* cls_f32,
-                          f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream) {
+                          f16* cls_f16, int n, int T, int D, float eps, hipStream_t stream, unsigned* nonfinite) {
     const int nv = (D / 4 + 63) / 64;
     const dim3 grid((n + 3) / 4), block(256);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(final_norm_cls_kernel<1>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
-        case 2: hipLaunchKernelGGL(final_norm_cls_kernel<2>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
-        case 3: hipLaunchKernelGGL(final_norm_cls_kernel<3>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
-        case 4: hipLaunchKernelGGL(final_norm_cls_kernel<4>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps); break;
+        case 1: hipLaunchKernelGGL(final_norm_cls_kernel<1>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps, nonfinite); break;
+        case 2: hipLaunchKernelGGL(final_norm_cls_kernel<2>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps, nonfinite); break;
+        case 3: hipLaunchKernelGGL(final_norm_cls_kernel<3>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps, nonfinite); break;
+        case 4: hipLaunchKernelGGL(final_norm_cls_kernel<4>, grid, block, 0, stream, x, gamma, beta, cls_f32, cls_f16, n, T, D, eps, nonfinite); break;
         default: return -1;
     }
     return CHECK_LAUNCH();

@@ -290,6 +290,12 @@ class DinoEncoder:
                    "cbas_enc_wait")
         return o16, o32
 
+    def check_finite(self) -> None:
+        """Raise if a batch completed since the last check produced a NaN / infinite CLS row (an activation left the range of
+        the arithmetic mode: cbas_enc_check_finite).  ``wait`` and the fused session's waits check by themselves; callers of the
+        stream-ordered forms (``encode_u8``, ``submit`` + ``wait_stream``) call this after synchronising."""
+        _lib.check(self._lib.cbas_enc_check_finite(self._h), "cbas_enc_check_finite")
+
     # -- per-kernel timing (HIP events inside the library) ------------------------------------------
     def profile(self, enable: bool) -> None:
         _lib.check(self._lib.cbas_enc_profile(self._h, int(bool(enable))), "cbas_enc_profile")

@@ -50,6 +50,7 @@ extern "C" {
 #define CBAS_EHIP         -2   /* a HIP runtime call failed */
 #define CBAS_ENOMEM       -3
 #define CBAS_ESTATE       -4   /* call sequence error (e.g. wait on an idle slot) */
+#define CBAS_ERANGE       -5   /* a frame's CLS row came out NaN / infinite: an activation left the arithmetic mode's range */
 
 #define CBAS_ABI_VERSION   10
 
@@ -163,6 +164,13 @@ int cbas_enc_wait_stream(cbas_enc* h, int slot, void* stream);
 int cbas_enc_submit_u8_host_dev(cbas_enc* h, int slot, const uint8_t* frames_host, int n, int height, int width,
                                 int64_t frame_stride, int64_t row_stride, int64_t pixel_stride,
                                 float* cls_f32_dev, uint16_t* cls_f16_dev, void* after_stream);
+/* The reference's fp32 arithmetic has no range limit; the fp16 activations of precision 0 (|value| < 65 504) and the
+ * split-fp16 operands of precision 4 (power-of-two scaled, see cbas_enc_config.precision) do.  Every forward pass tests its
+ * CLS rows (a non-finite value anywhere reaches them: every query attends to every key) and counts the frames that failed;
+ * cbas_enc_wait, cbas_fused_finish and cbas_fused_wait return CBAS_ERANGE instead of handing out such rows, and a caller of
+ * the stream-ordered forms (cbas_enc_forward_*, cbas_enc_submit_u8 + cbas_enc_wait_stream) asks here once its batches have
+ * completed.  Returns CBAS_OK or CBAS_ERANGE (cbas_last_error names the mode and the way out); clears the count. */
+int cbas_enc_check_finite(cbas_enc* h);
 /* The handle's copy stream (a hipStream_t), for work that should be ordered with its host->HBM copies rather than get a stream
  * of its own.  The fused session runs the head there: a HIP process has FOUR hardware queues by default (GPU_MAX_HW_QUEUES)
  * and its streams share them round-robin; with the two compute lanes, the copy stream AND a head stream all active, the

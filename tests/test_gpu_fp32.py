@@ -295,7 +295,7 @@ def test_fp32_dinov2_with_registers(golden_dir, precision):
         enc.close()
 
 
-@pytest.mark.parametrize("precision", PRECISIONS + ["default"])
+@pytest.mark.parametrize("precision", list(PRECISIONS) + ["default"])
 def test_fp32_file_level_dropins_against_the_references_encode_file(golden_dir, tmp_path, monkeypatch, precision):
     """encode_file / infer_file / encode_infer_file with a precision-3 encoder, against the `_cls.h5` rows the REFERENCE's
     own encode_file wrote for the same 600-frame 'video' (tests/golden/encode_file_b1layer.npz): the fp16 rows are the
@@ -372,6 +372,40 @@ def test_fp32_massive_activation_channels(precision):
         assert r.max() < CLS_TOL_F32, r.max()
     finally:
         enc.close()
+
+
+def test_out_of_range_activations_are_an_error_not_nan_rows():
+    """precision 4 splits its operands into fp16 halves after power-of-two scaling, so an activation beyond the
+    documented bound (|GELU output| x 4 < 65 504) overflows the high half, the low half becomes -inf and the three-term product
+    NaN - silently, while the mode is what an unmodified CBAS now gets by default.  The reference's fp32 arithmetic has no
+    such limit.  The final LayerNorm counts non-finite CLS rows and the wait returns CBAS_ERANGE (a RuntimeError here) naming
+    the way out; precision 3 computes the same frames."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.VIT_TINY
+    w = {k: v.copy() for k, v in W.synth_encoder_weights(cfg, 1234).items()}
+    w["model.layer.0.mlp.up_proj.bias"][3] = 40000.0                     # GELU(40 000) x 4 = 160 000 > 65 504
+    w["model.layer.0.mlp.down_proj.weight"][:, 3] *= 1e-4                # the fp32 result itself stays moderate
+    fr = synth.cage_frames(3, 8, 64, 64)
+    ref = PO.encode_frames(fr, w, cfg, batch=8)
+    assert np.isfinite(ref).all()
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=8, max_frame=(64, 64), precision=4)
+    try:
+        enc.submit_host(0, fr)
+        with pytest.raises(RuntimeError, match="non-finite CLS row.*precision 4.*CBAS_PRECISION=3"):
+            enc.wait(0, want_f32=True)
+        enc.submit_host(0, synth.cage_frames(4, 8, 64, 64) * 0)          # the handle stays usable; the count was cleared ...
+        with pytest.raises(RuntimeError, match="non-finite"):            # ... and these frames overflow as well (the bias does it)
+            enc.wait(0, want_f32=True)
+    finally:
+        enc.close()
+    enc3 = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=8, max_frame=(64, 64), precision=3)
+    try:
+        enc3.submit_host(0, fr)
+        _c16, c32 = enc3.wait(0, want_f32=True)
+        assert rel_rows(c32, ref).max() < CLS_TOL_F32
+    finally:
+        enc3.close()
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
