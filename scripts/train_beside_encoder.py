@@ -71,7 +71,7 @@ def run(seconds: float = 6.0, neighbours=("p4", "p0", "mfma")):
         try:
             while time.time() - t0 < seconds:
                 if nb == "mfma":
-                    _lib.check(lib.cbas_debug_mfma_neighbor(20000, None), "mfma_neighbor")
+                    _lib.check(lib.cbas_debug_mfma_neighbor(5000, None), "mfma_neighbor")      # ~2.5 ms launches: the trainer gets its turns
                 else:
                     enc.encode_u8(fr, want_f32=False)
                 torch.cuda.synchronize()
