@@ -1,4 +1,6 @@
 #!/bin/bash
+# Needs docs/experiments/r05_attention_split_pipelined.patch applied (the pipelined form was measured and NOT adopted: the library
+# as committed has the serial form only and ignores CBAS_ATTN_SPLIT_FORM).
 # Same-lease A/B of precision 4's attention forms (CBAS_ATTN_SPLIT_FORM=0 serial, 1 software-pipelined): bench.py --precision 4
 # alternating, then rocprofv3 kernel stats of each with one batch in flight.  Outputs: gpurun_out/attn_ab/.
 set -e

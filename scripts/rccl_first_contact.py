@@ -18,6 +18,9 @@ os.environ.setdefault("MASTER_PORT", "29533")
 os.environ["WORLD_SIZE"] = "1"
 os.environ["RANK"] = "0"
 os.environ["LOCAL_RANK"] = "0"
+# the HSA runtime reads this when it starts - i.e. at the first device call below, so it must be set BEFORE torch touches the
+# GPU (it used to be set after torch.cuda.set_device(0), where it had no effect on a stand-alone run: ADVICE r4)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -36,7 +39,6 @@ def main() -> None:
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     # init_from_env keeps a world of one un-initialised (the product never needs a group then); here the group is the point
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     step("init_process_group(nccl, world 1)", lambda: (dist.init_process_group(backend="nccl", rank=0, world_size=1), dist.get_backend())[1])
     step("barrier (creates the communicator)", lambda: (cdist.barrier(), "ok")[1])
 
