@@ -18,7 +18,10 @@ cross-half operand selection (operands moved into place first).  So the rule is 
 EXEC masks or LDS:
 
   R1  (build fails)  a v_pk_{add,mul,fma}_f32 whose op_sel has a 1: its LOW result half is formed from the HIGH half of a
-      source register pair.  No kernel of the library may contain one.  Ways out at the source level: `add_np` / `keep_scalar`
+      source register pair.  No kernel of the library may contain one.  v_pk_mov_b32 with op_sel is banned with them as a
+      precaution: the probe's `pk_mov` variant (the cross-half selection done by a move, the subtraction without any) ran
+      155 000 launches clean where the positive control on the same lease failed 5 of 157 000 - the arithmetic form is what
+      fails, the move probably not - but 0 where 5 were expected is not proof, and the ban costs three scalar adds in one kernel.  Ways out at the source level: `add_np` / `keep_scalar`
       (common.h) on one of the two scalar operations the compiler paired, or -packed-fp32-ops for a whole file whose kernels
       do not need packed math (build.py: the head's files).
   R2  (reported)     the mirror form, op_sel_hi with a 0 on a VGPR pair (HIGH result half from a LOW source half: the
@@ -44,7 +47,7 @@ REPORT = os.path.join(HERE, "asmcheck_report.json")
 
 _INSN = re.compile(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
 _FUNC = re.compile(r"^[0-9a-f]+ <([^>]+)>:$")
-_PK_F32 = re.compile(r"^v_pk_(add|mul|fma)_f32$")
+_PK_F32 = re.compile(r"^v_pk_((add|mul|fma)_f32|mov_b32)$")      # v_pk_mov_b32 shares the operand selection (see R1)
 _OP_SEL = re.compile(r"\bop_sel:\[([01,]+)\]")
 _OP_SEL_HI = re.compile(r"\bop_sel_hi:\[([01,]+)\]")
 

@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     for (int k = 0; k < NV; ++k) {
         const int idx = lane + 64 * k;
         v[k] = (idx < nvec) ? reinterpret_cast<const f32x4*>(xr)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
-        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        // add_np: the same sums in the same order, but not paired through a cross-half v_pk_mov_b32 / v_pk_add_f32 (common.h)
+        s += add_np(add_np(v[k][0], v[k][1]), add_np(v[k][2], v[k][3]));
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
@@ -469,8 +470,10 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     for (int k = 0; k < NV; ++k) {
         const int idx = lane + 64 * k;
         if (idx < nvec) {
+#pragma clang fp contract(off)            // four squares, three adds - as before (the packed form had no FMA either)
             const f32x4 d = v[k] - mean;
-            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            const f32x4 sq = d * d;
+            q += add_np(add_np(sq[0], sq[1]), add_np(sq[2], sq[3]));
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);

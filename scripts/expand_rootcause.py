@@ -25,6 +25,8 @@ s_waitcnt lgkmcnt(0); v_pk_add_f32 {b - c, a - b}; s_nop 0; v_sub_f32; ...; dive
                 moved into a fresh pair first, `v_pk_add_f32 v[8:9], v[10:11], v[18:19] neg_lo neg_hi` (the form the current
                 library kernel compiles to)
   pk_nooverlap  asm: the cross-half selection kept, result into a fresh pair (v[18:19]) instead of over src1
+  pk_mov        asm: the cross-half selection in a MOVE (v_pk_mov_b32 ... op_sel:[1,0] builds {c, b}), the subtraction itself without
+                operand selection: arithmetic or operand routing?
   pk_bcast      asm: the MIRROR form: {a - b, c - b} with b broadcast from the low register of its pair (op_sel_hi:[1,0]), then
                 (a - b) + (c - b): the scalar-broadcast form the compiler uses throughout the GEMM epilogues (asmcheck R2)
 
@@ -96,6 +98,11 @@ def build():
     variants["pk_bcast"] = _edit(base, seq, "\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v18, v11\n\tv_mov_b32_e32 v19, v9\n"
                                             "\tv_pk_add_f32 v[18:19], v[18:19], v[8:9] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n"
                                             "\tv_add_f32_e32 v18, v18, v19\n")
+    # the same cross-half selection in a MOVE: {c, b} = v_pk_mov_b32 of {b, c} with op_sel:[1,0] (low result = the source's HIGH
+    # register), then the subtraction without any operand selection - is it the arithmetic or the operand routing?
+    variants["pk_mov"] = _edit(base, seq, "\ts_waitcnt lgkmcnt(0)\n\tv_pk_mov_b32 v[18:19], v[8:9], v[8:9] op_sel:[1,0]\n\ts_nop 0\n"
+                                          "\tv_pk_add_f32 v[8:9], v[10:11], v[18:19] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n"
+                                          "\tv_sub_f32_e32 v18, v9, v8\n")
     # v18 / v19 are dead at the edited point: v18 is written by this very sequence, v19 only later (a temporary inside erff)
     return {k: _hsaco(k, v) for k, v in variants.items()}
 
@@ -179,7 +186,7 @@ def run(seconds: float, out_path, repeat: int = 64):
     import numpy as np, torch
     from cbas_amd import config as Cfg, weights as W, _lib
     from cbas_amd.head import ClassifierLSTMDeltas
-    names = tuple(os.environ.get("EXPAND_VARIANTS", "r4,nopk,erfbf,nop_after_pk,scalar_subs,nop_before_pk,wait_early,pk_plain,pk_nooverlap,pk_bcast").split(","))
+    names = tuple(os.environ.get("EXPAND_VARIANTS", "r4,nopk,erfbf,nop_after_pk,scalar_subs,nop_before_pk,wait_early,pk_plain,pk_nooverlap,pk_bcast,pk_mov").split(","))
     paths = {k: os.path.join(BIN, f"expand_r4_{k}.hsaco") for k in names}
     if not all(os.path.exists(p) for p in paths.values()):
         built = build()
