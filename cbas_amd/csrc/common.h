@@ -14,6 +14,38 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// Sum / max over the 64 lanes of a wave, every lane gets the result: the xor butterfly 32, 16, 8, 4, 2, 1 - the order and the
+// pairs of the __shfl_xor loops below (wave_sum / wave_max), hence the same bits (r5) - without its six LDS round trips (ds_bpermute):
+// v_permlane32_swap / v_permlane16_swap for the two cross-row steps (xor32_* / xor16_* below), then v_add_f32_dpp row_ror:8 / 4 /
+// 2 / 1 inside a row of 16.  row_ror:o hands lane i the value of lane (i + o) mod 16; after the step before it the values are
+// 2o-periodic within the row, so that lane holds what lane i ^ o holds.
+template <int CTRL> static __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float xor16_max(float a);
+static __device__ __forceinline__ float xor32_max(float a);
+static __device__ __forceinline__ float xor16_add(float a);
+static __device__ __forceinline__ float xor32_add(float a);
+static __device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = xor32_add(v);
+    v = xor16_add(v);
+    v += dpp_f32<0x128>(v);      // row_ror:8
+    v += dpp_f32<0x124>(v);      // row_ror:4
+    v += dpp_f32<0x122>(v);      // row_ror:2
+    v += dpp_f32<0x121>(v);      // row_ror:1
+    return v;
+}
+static __device__ __forceinline__ float wave_max_dpp(float v) {
+    v = xor32_max(v);
+    v = xor16_max(v);
+    v = fmaxf(v, dpp_f32<0x128>(v));
+    v = fmaxf(v, dpp_f32<0x124>(v));
+    v = fmaxf(v, dpp_f32<0x122>(v));
+    v = fmaxf(v, dpp_f32<0x121>(v));
+    return v;
+}
+// the __shfl_xor forms: everywhere but the encoder's LayerNorm kernels (whose waves are whole rows: EXEC is full at the call, which
+// the DPP forms need - a row_ror reads its neighbour lane whether or not that lane is active)
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -22,10 +22,7 @@ __device__ __forceinline__ f32x4 rope_rot(f32x4 a, f32x4 c, f32x4 b, f32x4 s) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int LN_BLOCK = 256;                  // columns per statistics block = one N tile of the producer
 // sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), every lane gets the total; fixed order, plain VALU
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
+// (dpp_f32<CTRL>: common.h)
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
     v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]

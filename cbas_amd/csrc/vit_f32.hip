@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
         // add_np: the same sums in the same order, but not paired through a cross-half v_pk_mov_b32 / v_pk_add_f32 (common.h)
         s += add_np(add_np(v[k][0], v[k][1]), add_np(v[k][2], v[k][3]));
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = wave_sum_dpp(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
             q += add_np(add_np(sq[0], sq[1]), add_np(sq[2], sq[3]));
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + eps);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int idx = lane + 64 * k;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
         v[k] = (idx < nvec) ? reinterpret_cast<const f32x4*>(xr)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = wave_sum_dpp(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
             q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + eps);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int idx = lane + 64 * k;
