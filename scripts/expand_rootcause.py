@@ -34,7 +34,7 @@ Amplification (cbas_head_debug_expand_repeat): every pass launches the probe ker
 each launch's rows with a reference taken on the idle device, capturing the differing rows: ~60 x the launches per second of
 the plain pipeline, so that per-variant counts mean something on a box where the fault is rare.
 """
-import json, os, re, subprocess, sys, threading, time
+import json, os, subprocess, sys, threading, time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROBE = os.path.join(REPO, "scripts", "probes", "expand_r4", "expand_r4.hip")
