@@ -545,6 +545,24 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             sends[:] = [s_ for s_ in sends if not all(w.is_completed() for w in s_[0])]
         publish(clip, _ST_OK, n, has_probs)
 
+    rescue_runner: list = []
+
+    def failed(clip: int, e: BaseException) -> None:
+        """A clip raised.  When its activations left the encoder's range (CBAS_ERANGE) it is run again, synchronously, through
+        the encoder's precision-3 twin (pipeline.range_fallback_for: the reference's fp32 has no range limit); anything else
+        - and a second failure - is logged and skipped, as EncodeThread does (workthreads.py:334-336)."""
+        try:
+            twin = P.range_fallback_for(encoder, e, paths[clip])
+            if twin is not None:
+                if not rescue_runner:
+                    rescue_runner.append(P.ClipRunner(twin, head, temperature, sessions=1))
+                deliver(clip, rescue_runner[0].run(paths[clip], None, progress_callback, device_out=nccl and rank != 0 and not lw))
+                return
+        except Exception as e2:  # noqa: BLE001
+            e = e2
+        print(f"ERROR during encoding for {paths[clip]} on rank {rank}: {e}")
+        publish(clip, _ST_FAILED, 0, False)
+
     # Clips are pipelined back to back where the results go to HOST memory (rank 0, gloo, one process): clip i+1 is pushed
     # before clip i's tail - its last batches, the tail classification, the copy-out - is waited for, so the GPU never idles
     # between clips (a clip's fixed cost was ~8 ms: 10 % of a 2 048-frame clip).  On RCCL ranks > 0 the rows leave from
@@ -584,8 +602,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 else:
                     cur = P._PendingClip(runner.run(paths[clip], None, progress_callback, device_out=True), None)
             except Exception as e:  # noqa: BLE001 - the queue survives a bad file (workthreads.py:334-336)
-                print(f"ERROR during encoding for {paths[clip]} on rank {rank}: {e}")
-                publish(clip, _ST_FAILED, 0, False)
+                failed(clip, e)
                 continue
             finally:
                 if prev is not None:                       # the clip before: its tail has had a whole clip's time to drain
@@ -594,14 +611,12 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                     try:
                         deliver(pc, pp.result())
                     except Exception as e:  # noqa: BLE001
-                        print(f"ERROR during encoding for {paths[pc]} on rank {rank}: {e}")
-                        publish(pc, _ST_FAILED, 0, False)
+                        failed(pc, e)
             if cur.done:                                   # nothing queued behind it (stand-in encoder, device outputs): now
                 try:
                     deliver(clip, cur.result())
                 except Exception as e:  # noqa: BLE001
-                    print(f"ERROR during encoding for {paths[clip]} on rank {rank}: {e}")
-                    publish(clip, _ST_FAILED, 0, False)
+                    failed(clip, e)
             else:
                 prev = (clip, cur)
         if prev is not None:
@@ -610,8 +625,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             try:
                 deliver(pc, pp.result())
             except Exception as e:  # noqa: BLE001
-                print(f"ERROR during encoding for {paths[pc]} on rank {rank}: {e}")
-                publish(pc, _ST_FAILED, 0, False)
+                failed(pc, e)
         for work, _r, _p in sends:
             for w in work:
                 _wait_done(w, gather_given_up)
@@ -673,6 +687,8 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                             if st_ != "ok":
                                 rec["cls_file"] = rec["csv_file"] = None
         runner.close()
+        for rr in rescue_runner:
+            rr.close()
     if recv_err:
         raise recv_err[0]
     return records if rank == 0 else None

@@ -162,7 +162,32 @@ class DinoEncoder:
             self._sessions = weakref.WeakSet()
         self._sessions.add(session)
 
+    def range_fallback(self) -> "DinoEncoder":
+        """The same model in precision 3 (fp32 end to end: no operand range limit), built on first use from this encoder's own
+        weight blob and closed with it.  The file paths re-encode a video here when its activations left this encoder's
+        range (CBAS_ERANGE: fp16 storage in precision 0, the scaled fp16 halves of precision 4) - the reference's fp32
+        arithmetic has no such limit, so a drop-in must not fail where the reference would have produced rows."""
+        twin = getattr(self, "_range_twin", None)
+        if twin is None:
+            twin = DinoEncoder.__new__(DinoEncoder)
+            twin.config, twin.device, twin._dev = self.config, self.device, self._dev
+            twin.max_batch, twin.max_frame = self.max_batch, self.max_frame
+            twin._lib, twin._blob = self._lib, self._blob
+            c = self._cfg_c
+            twin._cfg_c = _lib.EncConfig(c.hidden_size, c.intermediate_size, c.num_layers, c.num_heads, c.num_register_tokens,
+                                         c.patch_size, c.layer_norm_eps, c.rope_theta, c.max_batch, c.max_height, c.max_width,
+                                         3, c.use_rope, c.pos_embed_grid)
+            twin._h = None
+            twin.model_identifier = getattr(self, "model_identifier", "<in-memory>")
+            twin._create()
+            self._range_twin = twin
+        return twin
+
     def close(self):
+        twin = getattr(self, "_range_twin", None)
+        if twin is not None:
+            self._range_twin = None
+            twin.close()
         # fused sessions drain through this handle when they are destroyed: close them while it still exists
         for s in list(getattr(self, "_sessions", None) or ()):
             try:

@@ -231,6 +231,24 @@ def file_attrs(encoder=None) -> dict:
     return attrs
 
 
+def is_range_error(e: BaseException) -> bool:
+    """CBAS_ERANGE surfaced through the shims: a frame's CLS row came out non-finite (cbas_enc_check_finite)."""
+    return isinstance(e, RuntimeError) and "non-finite CLS row" in str(e)
+
+
+def range_fallback_for(encoder, e: BaseException, path: str):
+    """The precision-3 twin to re-encode `path` with, or None when `e` is not a range error (or CBAS_RANGE_FALLBACK=0, or the
+    encoder already is precision 3).  The reference computes in fp32 and has no operand range limit: where its rows are
+    finite ours must exist too, at precision 3's rate for that one video, with a line saying so."""
+    if not is_range_error(e) or os.environ.get("CBAS_RANGE_FALLBACK", "1") == "0":
+        return None
+    if not isinstance(encoder, DinoEncoder) or encoder.precision == 3:
+        return None
+    print(f"cbas_amd: {os.path.basename(path)}: activations left the range of precision {encoder.precision}; this video is "
+          "re-encoded in precision 3 (fp32 end to end, no range limit)")
+    return encoder.range_fallback()
+
+
 def encode_file(encoder: DinoEncoder, path: str, progress_callback=None, reader=None) -> Optional[str]:
     if not isinstance(encoder, DinoEncoder):
         raise TypeError("cbas_amd.encode_file needs a cbas_amd.DinoEncoder (the MI355X encoder); "
@@ -238,7 +256,13 @@ def encode_file(encoder: DinoEncoder, path: str, progress_callback=None, reader=
     own_reader = reader is None
     reader = reader if reader is not None else open_video(path)     # reader errors propagate (cbas.py:400-402)
     try:
-        return _encode_from_reader(encoder, path, reader, progress_callback)
+        try:
+            return _encode_from_reader(encoder, path, reader, progress_callback)
+        except RuntimeError as e:
+            twin = range_fallback_for(encoder, e, path)
+            if twin is None:
+                raise
+            return _encode_from_reader(twin, path, reader, progress_callback)
     finally:
         if own_reader and hasattr(reader, "close"):
             reader.close()
@@ -1064,8 +1088,15 @@ def encode_infer_file(encoder: DinoEncoder, model, path: str, dataset_name: str,
         if len(reader) == 0:
             print(f"Warning: Video {path} contains no frames. Skipping.")
             return None, None
-        cls_path, res = _write_cls_while_encoding(path, encoder, lambda sink: _runner_for(encoder, head, temperature).run(
-            path, reader, progress_callback, rows_sink=sink))
+        try:
+            cls_path, res = _write_cls_while_encoding(path, encoder, lambda sink: _runner_for(encoder, head, temperature).run(
+                path, reader, progress_callback, rows_sink=sink))
+        except RuntimeError as e:
+            twin = range_fallback_for(encoder, e, path)
+            if twin is None:
+                raise
+            cls_path, res = _write_cls_while_encoding(path, twin, lambda sink: _runner_for(twin, head, temperature).run(
+                path, reader, progress_callback, rows_sink=sink))
     finally:
         if own_reader and hasattr(reader, "close"):
             reader.close()

@@ -408,6 +408,58 @@ def test_out_of_range_activations_are_an_error_not_nan_rows():
         enc3.close()
 
 
+def test_file_paths_fall_back_to_precision3_when_the_range_is_left(tmp_path, capsys):
+    """The reference's fp32 arithmetic has no operand range limit, so a drop-in must produce rows wherever the reference does:
+    when a video's activations leave the range of the default mode (precision 4) the file paths re-encode THAT video through
+    the encoder's precision-3 twin - `encode_file`, `encode_infer_file` and `dist.encode_files` alike - and say so; the rows are
+    the fp32 oracle's (5e-6 before the fp16 store).  CBAS_RANGE_FALLBACK=0 restores the error."""
+    from cbas_amd import dist as cdist, pipeline as P, h5io
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.VIT_TINY
+    w = {k: v.copy() for k, v in W.synth_encoder_weights(cfg, 1234).items()}
+    w["model.layer.0.mlp.up_proj.bias"][3] = 40000.0                     # GELU(40 000) x 4 overflows the fp16 high half
+    w["model.layer.0.mlp.down_proj.weight"][:, 3] *= 1e-4
+    frames = synth.cage_frames(3, 90, 64, 64)
+    ref = PO.encode_frames(frames, w, cfg, batch=8)
+    ref16 = ref.astype(np.float16)
+    names = ["eating", "drinking", "rearing", "climbing", "digging", "nesting", "resting", "grooming", "exploring"]
+    head = make_head(cfg.hidden_size)
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=16, max_frame=(64, 64), precision=4)
+
+    def rows_of(path):
+        with h5io.ClsReader(path) as r:
+            return r.read(0, 90)
+
+    def close_enough(got):
+        d = np.abs(got.astype(np.float32) - ref16.astype(np.float32))
+        return (got != ref16).mean() < 2e-2 and (d <= np.abs(ref16.astype(np.float32)) * 2.0 ** -10 + 4e-6).all()
+    try:
+        for sub in ("a", "b", "c"):
+            (tmp_path / sub).mkdir()
+            np.save(str(tmp_path / sub / "vid.npy"), frames)
+        out = P.encode_file(enc, str(tmp_path / "a" / "vid.npy"))
+        assert "re-encoded in precision 3" in capsys.readouterr().out
+        assert close_enough(rows_of(out))
+        h5b, csvb = P.encode_infer_file(enc, head, str(tmp_path / "b" / "vid.npy"), "ds", names)
+        assert "re-encoded in precision 3" in capsys.readouterr().out
+        assert open(out, "rb").read() == open(h5b, "rb").read() and os.path.getsize(csvb) > 0
+        recs = cdist.encode_files([str(tmp_path / "c" / "vid.npy")], enc, head=head, dataset_name="ds", behaviors=names)
+        assert recs[0]["status"] == "ok" and open(recs[0]["cls_file"], "rb").read() == open(out, "rb").read()
+        assert open(recs[0]["csv_file"], "rb").read() == open(csvb, "rb").read()
+        # the encoder itself is still the precision-4 one and still works on frames inside its range? (these weights overflow
+        # on every frame, so only the switch is checked here)
+        assert enc.precision == 4 and enc.range_fallback().precision == 3
+        os.environ["CBAS_RANGE_FALLBACK"] = "0"
+        try:
+            with pytest.raises(RuntimeError, match="non-finite CLS row"):
+                P.encode_file(enc, str(tmp_path / "a" / "vid.npy"))
+        finally:
+            del os.environ["CBAS_RANGE_FALLBACK"]
+    finally:
+        enc.close(); head.close()
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_fp32_e2e_dinov2_default_encoder_labels_identical(golden_dir, precision):
     """CBAS's DEFAULT encoder family end to end: DINOv2-with-registers ViT-B/14 through the reference's own DinoEncoder
