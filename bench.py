@@ -56,6 +56,8 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0      # dense fp8 (block-scaled) MFMA peak, same gu
 MFMA_F32_PEAK_TFLOPS = 157.3       # f32-input MFMA (v_mfma_f32_16x16x4_f32) = the fp32 vector peak, same guide
 BEHAVIORS = 9
 SEQ_LEN = 31
+MODEL_LABEL = {"vits16": "DINOv3 ViT-S/16", "vitb16": "DINOv3 ViT-B/16", "vitl16": "DINOv3 ViT-L/16", "tiny": "tiny test ViT",
+               "dinov2regb14": "DINOv2-with-registers ViT-B/14 (CBAS's default encoder family)", "dinov2regtiny": "tiny DINOv2-with-registers"}
 
 
 def cpu_baseline(model: str, hw: int, frames: int, batch: int) -> dict:
@@ -667,7 +669,7 @@ def main() -> None:
         "metric": METRIC, "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm,
         "ms_per_step": round(dt_value / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {2: "fp8", 3: "f32", 4: "f32 (GEMM products: 3-term f16 split)"}.get(args.precision, "f16"), "data": "synthetic",
-        "config": {"workload": f"DINOv3 ViT-{args.model[3:].upper()} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
+        "config": {"workload": f"{MODEL_LABEL.get(args.model, args.model)} {K * B}-frame synthetic {args.hw}x{args.hw} RGB clip per GPU, "
                                f"batch={B}, chunked encode + BiLSTM head (C={BEHAVIORS}, seq_len={SEQ_LEN})",
                    "input": ("uint8 RGB (n,H,W,3) in pinned host memory -> " +
                              ("channel 1 kept by the decode-ahead thread while it fills page-locked ring pieces (cbas_pick_channel_u8) "
