@@ -508,11 +508,18 @@ constexpr int AIMG = AKB * 256;             // bytes of one K or V block image
 
 __global__ __launch_bounds__(512, 2) void attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                float* __restrict__ out, int T, int D, int n_heads, int qblocks,
-                                                               float split_scale) {
+                                                               float split_scale, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
-    const int pair = blockIdx.x / qblocks, qb = blockIdx.x - pair * qblocks;
+    // XCD-aware workgroup -> (frame, head, query block) map (r5).  The hardware hands consecutive workgroup ids to the eight XCDs
+    // round-robin, so with the plain map (id = pair * qblocks + qb) the query blocks of one (frame, head) land on DIFFERENT
+    // XCDs and each XCD's L2 fetches that head's K and V from the fabric again - and the ablation of this kernel
+    // shows 60 % of its time is exactly that stream.  Here XCD x's k-th workgroup takes pair x + 8 (k / qblocks), query block
+    // k % qblocks: the query blocks of a pair run back to back on ONE XCD and the second one finds K and V in its L2.
+    const int xcd_k = blockIdx.x >> 3;
+    const int pair = (blockIdx.x & 7) + 8 * (xcd_k / qblocks), qb = xcd_k % qblocks;
+    if (pair >= npairs) return;                                        // the grid is rounded up to 8 x qblocks (whole workgroups leave)
     const int b = pair / n_heads, hd = pair - b * n_heads;
     const size_t ld = (size_t)3 * D;
     const float* qbase = qkv + (size_t)b * T * ld + hd * 64;
@@ -679,13 +686,26 @@ __device__ __forceinline__ float exp_raw(float d) {
     return fmaf(e, r * 0.693147181f, e);
 }
 
+// Measurement aid (scripts/attn_ablate.sh): -DCBAS_ATTN_ABLATE=<bits> compiles parts of a key block OUT - the
+// results are then garbage, the point is what each part costs: 1 the softmax's exponentials and hi / lo split, 2 the P.V MFMAs
+// and V's LDS reads, 4 V's LDS reads only (the MFMAs run on constant fragments), 8 the S MFMAs and K's LDS reads.  0 (default).
+#ifndef CBAS_ATTN_ABLATE
+#define CBAS_ATTN_ABLATE 0
+#endif
 __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                  float* __restrict__ out, int T, int D, int n_heads, int qblocks,
-                                                                 float out_scale) {
+                                                                 float out_scale, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [buf][K_hi | K_lo | V_hi | V_lo][64 keys][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
-    const int pair = blockIdx.x / qblocks, qb = blockIdx.x - pair * qblocks;
+    // XCD-aware workgroup -> (frame, head, query block) map (r5).  The hardware hands consecutive workgroup ids to the eight XCDs
+    // round-robin, so with the plain map (id = pair * qblocks + qb) the query blocks of one (frame, head) land on DIFFERENT
+    // XCDs and each XCD's L2 fetches that head's K and V from the fabric again - and the ablation of this kernel
+    // shows 60 % of its time is exactly that stream.  Here XCD x's k-th workgroup takes pair x + 8 (k / qblocks), query block
+    // k % qblocks: the query blocks of a pair run back to back on ONE XCD and the second one finds K and V in its L2.
+    const int xcd_k = blockIdx.x >> 3;
+    const int pair = (blockIdx.x & 7) + 8 * (xcd_k / qblocks), qb = xcd_k % qblocks;
+    if (pair >= npairs) return;                                        // the grid is rounded up to 8 x qblocks (whole workgroups leave)
     const int b = pair / n_heads, hd = pair - b * n_heads;
     const size_t ldb = (size_t)3 * D * 4;                              // bytes per token row
     const char* qbase = reinterpret_cast<const char*>(qkv) + (size_t)b * T * ldb + (size_t)hd * 256;
@@ -742,6 +762,9 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         for (int kt = 0; kt < 4; ++kt) {
             if (!FULL && kt >= nkt) { s[kt] = f32x4{NEG, NEG, NEG, NEG}; continue; }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#if CBAS_ATTN_ABLATE & 8
+            acc = f32x4{(float)(kt + li), (float)g, (float)(kb & 3), 1.0f};
+#else
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
@@ -750,6 +773,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
             }
+#endif
             s[kt] = acc;
         }
         if (!FULL) {                                              // only a partial block can hold keys past T
@@ -776,12 +800,19 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+#if CBAS_ATTN_ABLATE & 1
+                    const f16 h = (f16)fminf(fabsf(s[2 * grp + u][r]), 1.0f);      // bounded (the range guard stays quiet), still depends on S
+                    ph[grp][4 * u + r] = h;
+                    pl[grp][4 * u + r] = h;
+                    psum += 1.0f;
+#else
                     const float pv = exp_raw(s[2 * grp + u][r] - mnew);
                     psum += pv;
                     const float x = pv * ATT_PS;
                     const f16 h = (f16)x;
                     ph[grp][4 * u + r] = h;
                     pl[grp][4 * u + r] = (f16)(x - (float)h);
+#endif
                 }
         lrun = lrun * alpha + psum;
         mrun = mnew;
@@ -795,13 +826,23 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
             for (int dt = 0; dt < 4; ++dt) {
                 const int col = 16 * dt + 4 * (li & 3);
                 union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
+#if CBAS_ATTN_ABLATE & 2
+                o[dt][0] += (float)ph[s2][0] + (float)pl[s2][1];               // keeps P alive; no reads, no MFMAs
+                (void)krow; (void)col; (void)uh; (void)ul;
+#else
+#if CBAS_ATTN_ABLATE & 4
+                uh.v = qh[s2]; ul.v = ql[s2];                                  // constant fragments instead of V's LDS reads
+                (void)krow; (void)col;
+#else
                 uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
                 uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
                 ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
                 ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
+#endif
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
+#endif
             }
         }
     };
@@ -924,7 +965,8 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
     }
     if (q_cls) nw = 4;
     const int qblocks = (ntiles + nw - 1) / nw;
-    const int64_t grid = (int64_t)n * n_heads * qblocks;
+    const int npairs = n * n_heads;
+    const int64_t grid = (int64_t)((npairs + 7) / 8) * 8 * qblocks;        // whole groups of 8 pairs: see the kernels' workgroup map
     if (grid > 0x7fffffff) return -1;
     if (split_scale > 0.f) {                                // precision 4: q | k | v arrive split (store_head_split4)
         static bool attr2 = false;
@@ -936,9 +978,10 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
             attr2 = true;
         }
         hipLaunchKernelGGL(attention_split_kernel, dim3((unsigned)grid), dim3(nw * 64), lds2, stream, qkv, q_cls, out, T, D, n_heads,
-                           qblocks, split_scale);
+                           qblocks, split_scale, npairs);
         return CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks, split_scale);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks, split_scale,
+                       npairs);
     return CHECK_LAUNCH();
 }
