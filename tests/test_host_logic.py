@@ -393,3 +393,39 @@ def test_asmcheck_bans_the_packed_form_round5_identified():
     for obj in ("head_kernels.o", "head_train_kernels.o"):
         ks = A.disassemble_object(os.path.join(B.HERE, "build", obj))
         assert ks and not [mn for insns in ks.values() for mn, _, _ in insns if mn.startswith("v_pk_") and mn.endswith("_f32")], obj
+
+
+def test_asmcheck_catches_the_form_in_real_compiler_output(tmp_path):
+    """The checker against hipcc's own output: two subtractions whose operands sit in opposite halves of their register pairs
+    compile to `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` - the banned form - and the same source with
+    common.h's `keep_scalar` on one of them does not."""
+    import shutil
+    import subprocess
+    from cbas_amd import asmcheck as A
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not present")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "k.hip"
+    src.write_text('''
+#include "common.h"
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ void crossed(const f32x2* a, const f32x2* b, f32x2* c) {
+    const int i = threadIdx.x;
+    const f32x2 x = a[i], y = b[i];
+    c[i] = f32x2{x[0] - y[1], x[1] - y[0]};
+}
+__global__ void pinned(const f32x2* a, const f32x2* b, f32x2* c) {
+    const int i = threadIdx.x;
+    const f32x2 x = a[i], y = b[i];
+    c[i] = f32x2{keep_scalar(x[0] - y[1]), x[1] - y[0]};
+}
+''')
+    obj = tmp_path / "k.o"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(B.HERE, "csrc"), "-c", str(src), "-o", str(obj)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = A.check_objects([str(obj)])
+    assert rep["kernels"] == 2
+    kernels_with_r1 = {f["kernel"] for f in rep["R1"]}
+    assert any("crossed" in k for k in kernels_with_r1), rep
+    assert not any("pinned" in k for k in kernels_with_r1), rep["R1"]
