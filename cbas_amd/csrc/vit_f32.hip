@@ -688,13 +688,14 @@ __device__ __forceinline__ float exp_raw(float d) {
 
 // Measurement aid (scripts/attn_ablate.sh): -DCBAS_ATTN_ABLATE=<bits> compiles parts of a key block OUT - the
 // results are then garbage, the point is what each part costs: 1 the softmax's exponentials and hi / lo split, 2 the P.V MFMAs
-// and V's LDS reads, 4 V's LDS reads only (the MFMAs run on constant fragments), 8 the S MFMAs and K's LDS reads.  0 (default).
+// and V's LDS reads, 4 V's LDS reads only (the MFMAs run on constant fragments), 8 the S MFMAs and K's LDS reads, 16 the K / V
+// stream itself (no LDS-DMA; barriers stay), 32 the final stores.  0 (default).
 #ifndef CBAS_ATTN_ABLATE
 #define CBAS_ATTN_ABLATE 0
 #endif
 __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
                                                                  float* __restrict__ out, int T, int D, int n_heads, int qblocks,
-                                                                 float out_scale, int npairs) {
+                                                                 float out_scale, int npairs, int total_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [buf][K_hi | K_lo | V_hi | V_lo][64 keys][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
@@ -703,15 +704,47 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
     // XCDs and each XCD's L2 fetches that head's K and V from the fabric again - and the ablation of this kernel
     // shows 60 % of its time is exactly that stream.  Here XCD x's k-th workgroup takes pair x + 8 (k / qblocks), query block
     // k % qblocks: the query blocks of a pair run back to back on ONE XCD and the second one finds K and V in its L2.
-    const int xcd_k = blockIdx.x >> 3;
-    const int pair = (blockIdx.x & 7) + 8 * (xcd_k / qblocks), qb = xcd_k % qblocks;
-    if (pair >= npairs) return;                                        // the grid is rounded up to 8 x qblocks (whole workgroups leave)
-    const int b = pair / n_heads, hd = pair - b * n_heads;
+    // PERSISTENT form (r5): the grid may be smaller than the number of (frame, head, query block) items - a multiple of 8, so that
+    // a workgroup's items all keep its XCD - and every workgroup walks items id, id + gridDim.x, ...  (grid == total_items: one
+    // item each, the earlier form.)
+    // The K / V ring runs ON across items: the slot index is a block counter of the workgroup (gb), and during an item's last
+    // key block the free slot receives the NEXT item's first block - the stream has no bubble at an item boundary and the
+    // first wait of an item finds its block landed under the previous item's tail.
     const size_t ldb = (size_t)3 * D * 4;                              // bytes per token row
-    const char* qbase = reinterpret_cast<const char*>(qkv) + (size_t)b * T * ldb + (size_t)hd * 256;
-    const char* kbase = qbase + (size_t)D * 4;
-    const char* vbase = qbase + (size_t)D * 8;
     const int g = lane >> 4, li = lane & 15;
+    const int nkb = (T + AKB - 1) / AKB;
+    const int pr = lane >> 3, pos = lane & 7;
+    auto item_pair = [&](int it) { const int k_ = it >> 3; return (it & 7) + 8 * (k_ / qblocks); };
+    auto stage = [&](int buf, int pair_, int kb) {                     // block kb of (frame, head) pair_ into ring slot buf
+        const int b_ = pair_ / n_heads, hd_ = pair_ - b_ * n_heads;
+        const char* kb_ = reinterpret_cast<const char*>(qkv) + (size_t)b_ * T * ldb + (size_t)hd_ * 256 + (size_t)D * 4;
+        const char* vb_ = kb_ + (size_t)D * 4;
+        char* base = smem + buf * 4 * SIMG;
+        for (int p = wave; p < 32; p += nwaves) {                      // 4 images x 8 pieces of 8 rows
+            const int img = p >> 3, piece = p & 7;
+            const int r = piece * 8 + pr;
+            int gr = kb * AKB + r;
+            gr = gr < T ? gr : T - 1;                                  // rows past T re-read row T-1: finite, masked below
+            const int chunk = img < 2 ? (pos ^ ((r >> 1) & 7)) : ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1));
+            const char* src = (img < 2 ? kb_ : vb_) + (size_t)gr * ldb + (img & 1) * 128 + chunk * 16;
+#if !(CBAS_ATTN_ABLATE & 16)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + img * SIMG + piece * 1024), 16, 0, 0);
+#else
+            (void)src; (void)base;
+#endif
+        }
+    };
+    // first item with work of this workgroup (items past npairs * qblocks are padding of the XCD map)
+    auto next_item = [&](int it) { while (it < total_items && item_pair(it) >= npairs) it += gridDim.x; return it; };
+    int item = next_item(blockIdx.x);
+    int gb = 0;                                                        // blocks consumed so far: ring slot = gb & 1
+    if (item < total_items) stage(0, item_pair(item), 0);
+    for (; item < total_items;) {
+    const int following = next_item(item + gridDim.x);
+    const int xcd_k = item >> 3;
+    const int pair = item_pair(item), qb = xcd_k % qblocks;
+    const int b = pair / n_heads, hd = pair - b * n_heads;
+    const char* qbase = reinterpret_cast<const char*>(qkv) + (size_t)b * T * ldb + (size_t)hd * 256;
     const int nq = q_cls ? 1 : T;
     const int qt = qb * nwaves + wave;
     const bool active = qt * 16 < nq;                                  // wave-uniform
@@ -725,21 +758,6 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         ql[h2] = *reinterpret_cast<const f16x8*>(qsrc + 128 + (4 * h2 + g) * 16);
     }
 
-    const int nkb = (T + AKB - 1) / AKB;
-    const int pr = lane >> 3, pos = lane & 7;
-    auto stage = [&](int buf, int kb) {
-        char* base = smem + buf * 4 * SIMG;
-        for (int p = wave; p < 32; p += nwaves) {                      // 4 images x 8 pieces of 8 rows
-            const int img = p >> 3, piece = p & 7;
-            const int r = piece * 8 + pr;
-            int gr = kb * AKB + r;
-            gr = gr < T ? gr : T - 1;                                  // rows past T re-read row T-1: finite, masked below
-            const int chunk = img < 2 ? (pos ^ ((r >> 1) & 7)) : ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1));
-            const char* src = (img < 2 ? kbase : vbase) + (size_t)gr * ldb + (img & 1) * 128 + chunk * 16;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + img * SIMG + piece * 1024), 16, 0, 0);
-        }
-    };
-    stage(0, 0);
 
     // scores stay in the accumulator's units (x ATT_QS ATT_KS: max and differences scale exactly); the factor is undone
     // inside the exponential's constant.  Masked scores are a large finite negative, not -inf: exp_raw needs no clamp.
@@ -751,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
 
     auto block = [&](int kb, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
-        const char* Kh = smem + (kb & 1) * 4 * SIMG;
+        const char* Kh = smem + ((gb + kb) & 1) * 4 * SIMG;
         const char* Kl = Kh + SIMG;
         const char* Vh = Kl + SIMG;
         const char* Vl = Vh + SIMG;
@@ -849,7 +867,8 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
     for (int kb = 0; kb < nkb; ++kb) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
         __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
-        if (kb + 1 < nkb) stage((kb + 1) & 1, kb + 1);
+        if (kb + 1 < nkb) stage((gb + kb + 1) & 1, pair, kb + 1);
+        else if (following < total_items) stage((gb + kb + 1) & 1, item_pair(following), 0);      // the next item's first block
         if (active) {
             // a full block (64 real keys: every block but the last) runs without the per-tile tests, so that its four key
             // tiles are four independent MFMA chains in one basic block; same operations per query either way
@@ -857,7 +876,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
             else block(kb, std::integral_constant<bool, false>{});
         }
     }
-    if (!active) return;
+    if (active) {
     lrun = xor16_add(lrun);
     lrun = xor32_add(lrun);
     if (q < nq) {
@@ -866,10 +885,18 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const f32x4 v = (o[dt] * (1.0f / (ATT_VS * ATT_PS))) / lrun;
+#if CBAS_ATTN_ABLATE & 32
+            if (v[0] == 123.456f) store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);      // never true: no stores
+#else
             store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);
+#endif
         }
         (void)inv;
     }
+    }                                                                  // active
+    gb += nkb;
+    item = following;                                                  // (no barrier here: the next item's first block waits + barriers as every block does)
+    }                                                                  // items
 }
 
 
@@ -977,8 +1004,19 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
                 return -2;
             attr2 = true;
         }
-        hipLaunchKernelGGL(attention_split_kernel, dim3((unsigned)grid), dim3(nw * 64), lds2, stream, qkv, q_cls, out, T, D, n_heads,
-                           qblocks, split_scale, npairs);
+        // persistent launch (default; CBAS_ATTN_PERSIST=0: one workgroup per item): at most two workgroups per CU - what fits -
+        // each walking several items with its K / V ring running on across them; a multiple of 8 keeps the XCD map.  Rows are
+        // bit-identical either way; 59.5 -> 56.0 us per layer at ViT-B batch 64 on one lease (profiles/r05_attention_ablation.json)
+        static const int persist = [] { const char* e = getenv("CBAS_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
+        int64_t launch = grid;
+        if (persist) {
+            static int cus = 0;
+            if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+            const int64_t cap = (int64_t)(2 * cus) / 8 * 8;
+            if (cap > 0 && launch > cap) launch = cap;
+        }
+        hipLaunchKernelGGL(attention_split_kernel, dim3((unsigned)launch), dim3(nw * 64), lds2, stream, qkv, q_cls, out, T, D, n_heads,
+                           qblocks, split_scale, npairs, (int)grid);
         return CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)grid), dim3(nw * 64), lds, stream, qkv, q_cls, out, T, D, n_heads, qblocks, split_scale,

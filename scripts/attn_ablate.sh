@@ -12,7 +12,7 @@ python -m cbas_amd.build --force --no-asm-check > /dev/null      # the object fi
 OBJS=$(ls cbas_amd/build/*.o | grep -v '\.debug\.o' | grep -v 'vit_f32.o' | grep -v api_debug)
 echo "[" > $OUT/summary.json
 first=1
-for a in 0 1 2 4 8 3 9 10 11 15; do
+for a in ${ABLATIONS:-0 1 2 4 8 3 9 10 11 15 31 47 63}; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -I cbas_amd/csrc -DCBAS_ATTN_ABLATE=$a -c cbas_amd/csrc/vit_f32.hip -o /tmp/vit_f32_ab.o 2>/dev/null
   hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=cbas_amd/csrc/exports.map -o cbas_amd/libcbas_mi355x.so $OBJS /tmp/vit_f32_ab.o
   python bench.py --precision 4 --no-gates --no-label-exact --no-cpu-baseline --no-host-path --files 0 --steps 40 --warmup 3 > $OUT/bench_ab$a.json 2>> $OUT/bench.err
