@@ -48,6 +48,26 @@ assert workthreads.cbas.DinoEncoder is DinoEncoder and workthreads.cbas.encode_f
 assert workthreads.cbas.infer_file is P.infer_file and workthreads.classifier_head.ClassifierLSTMDeltas is ClassifierLSTMDeltas
 assert workthreads.cbas.train_lstm_model.__module__ == "cbas_amd.train"
 
+# what startup_page.py:66-69 gets when it builds its encoder through the patched name - cbas.DinoEncoder(model_identifier=...,
+# device=...), no precision anywhere: the contract-complete mode (precision 4: CLS ~1e-6, every label the reference's), and the
+# fp16-operand fast mode only on request (VERDICT r4 item 4)
+import cbas_amd.encoder as E
+assert E.DEFAULT_PRECISION == 4
+ck = os.path.join(TMP, "enc_ck")
+W.save_encoder_checkpoint(ck, C.VIT_TINY, W.synth_encoder_weights(C.VIT_TINY, 3))
+seen = []
+real_init = E.DinoEncoder._init
+E.DinoEncoder._init = lambda self, cfg, w, dev, mb, mf, precision: seen.append(int(precision))
+try:
+    os.environ.pop("CBAS_PRECISION", None)
+    cbas.DinoEncoder(model_identifier=ck, device="cuda")
+    os.environ["CBAS_PRECISION"] = "0"
+    cbas.DinoEncoder(model_identifier=ck, device="cuda")
+finally:
+    os.environ.pop("CBAS_PRECISION", None)
+    E.DinoEncoder._init = real_init
+assert seen == [4, 0], seen
+
 # a bundle as TrainingThread writes it, loaded by the reference's own ClassificationThread._load_model
 ENC = "facebook/dinov3-vitb16-pretrain-lvd1689m"
 names = ["a", "b", "c", "d", "e"]
