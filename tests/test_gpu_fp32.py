@@ -374,6 +374,39 @@ def test_fp32_massive_activation_channels(precision):
         enc.close()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("family", ["dinov3", "dinov2"])
+def test_fp32_non_square_and_ragged_frames(precision, family):
+    """The reference takes whatever frame size the video has (`cbas.py:431-435`: no resize): non-square frames, and sizes that
+    are not a multiple of the patch (the convolution drops the remainder; the RoPE grid / the interpolated DINOv2 position table
+    follow the patch grid), in one encoder handle, in precisions 3 and 4 - CLS within 5e-6 of the fp32 oracle for every size."""
+    from cbas_amd.encoder import DinoEncoder
+    from oracle import pipeline_oracle as PO
+    cfg = C.VIT_TINY if family == "dinov3" else C.DINOV2_REG_TINY
+    ps = cfg.patch_size
+    w = W.synth_encoder_weights(cfg, 77)
+    sizes = [(4 * ps, 6 * ps), (5 * ps, 3 * ps), (4 * ps + 6, 5 * ps + ps - 1), (2 * ps, 2 * ps)]
+    hmax, wmax = max(h for h, _ in sizes), max(w_ for _, w_ in sizes)
+    enc = DinoEncoder.from_weights(cfg, w, "cuda", max_batch=8, max_frame=(hmax, wmax), precision=precision)
+    try:
+        for i, (H, Wd) in enumerate(sizes):
+            fr = synth.cage_frames(20 + i, 6, H, Wd)
+            if family == "dinov3":
+                ref = PO.encode_frames(fr, w, cfg, batch=6)
+            else:                                                     # oracle/dinov2_oracle.py: interpolated position table, key bias
+                from oracle import dinov2_oracle as O2, vit_oracle as V
+                px = np.repeat(V.preprocess_green(fr)[:, None], 3, 1)
+                ref = O2.forward(px, W.canonical_encoder_weights(cfg, w), cfg)[:, 0]
+            _, c32 = enc.encode_u8(torch.from_numpy(fr).cuda())
+            torch.cuda.synchronize()
+            enc.check_finite()
+            r = rel_rows(c32.cpu().numpy(), ref)
+            print(f"[{family} precision {precision}] {H}x{Wd}: CLS rel err max {r.max():.2e}")
+            assert r.max() < CLS_TOL_F32, (H, Wd, float(r.max()))
+    finally:
+        enc.close()
+
+
 def test_out_of_range_activations_are_an_error_not_nan_rows():
     """precision 4 splits its operands into fp16 halves after power-of-two scaling, so an activation beyond the
     documented bound (|GELU output| x 4 < 65 504) overflows the high half, the low half becomes -inf and the three-term product
