@@ -114,6 +114,7 @@ struct cbas_enc {
     float2* lnst = nullptr;            // [4][rows_cap] per-row LayerNorm statistics by 256-column block
     int last_rows = 0;
     hipStream_t compute = nullptr, copy = nullptr;
+    hipStream_t aux = nullptr;          // cbas_enc_check_finite's 4-byte copies: not the NULL stream (torch's default stream is one: a copy there would wait for the caller's own work)
     Slot slots[CBAS_ENC_SLOTS];
     int64_t slot_bytes = 0;             // pinned staging / device input bytes per slot: max_batch x H x W x 4 channels
     // Two batches in flight: the asynchronous entry points (cbas_enc_submit_u8 / ..._host) alternate two
@@ -705,6 +706,7 @@ extern "C" void cbas_enc_destroy(cbas_enc* h) {
         if (b) (void)hipFree(b);
     if (h->compute) (void)hipStreamDestroy(h->compute);
     if (h->copy) (void)hipStreamDestroy(h->copy);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     delete h;
 }
 
@@ -754,6 +756,7 @@ extern "C" int cbas_enc_create(const cbas_enc_config* cfg, const float* weights_
 
     CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc(&h->blob, n_weights * sizeof(float)));
     CREATE_TRY(hipMemcpy(h->blob, weights_host, n_weights * sizeof(float), hipMemcpyHostToDevice));
 
@@ -1321,10 +1324,11 @@ extern "C" int cbas_enc_check_finite(cbas_enc* h) {
     if (!h) return cbas_fail(CBAS_EINVAL, "null encoder handle");
     HIP_TRY(hipSetDevice(h->device));
     unsigned n = 0;
-    HIP_TRY(hipMemcpy(&n, h->nonfinite_dev, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&n, h->nonfinite_dev, sizeof(n), hipMemcpyDeviceToHost, h->aux));
+    HIP_TRY(hipStreamSynchronize(h->aux));
     if (!n) return CBAS_OK;
-    const unsigned zero = 0;
-    HIP_TRY(hipMemcpy(h->nonfinite_dev, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(h->nonfinite_dev, 0, sizeof(unsigned), h->aux));
+    HIP_TRY(hipStreamSynchronize(h->aux));
     return cbas_fail(CBAS_ERANGE, "%u frame(s) produced a non-finite CLS row: an activation left the range of precision %d%s",
                      n, h->cfg.precision,
                      h->cfg.precision == 4 ? " (operands are split into fp16 halves after power-of-two scaling: |GELU output| < 16 376, "
