@@ -18,12 +18,10 @@ cross-half operand selection (operands moved into place first).  So the rule is 
 EXEC masks or LDS:
 
   R1  (build fails)  a v_pk_{add,mul,fma}_f32 whose op_sel has a 1: its LOW result half is formed from the HIGH half of a
-      source register pair.  No kernel of the library may contain one.  v_pk_mov_b32 with op_sel is banned with them as a
-      precaution: the probe's `pk_mov` variant (the cross-half selection done by a move, the subtraction without any) ran
-      155 000 launches clean where the positive control on the same lease failed 5 of 157 000 - the arithmetic form is what
-      fails, the move probably not - but 0 where 5 were expected is not proof, and the ban costs three scalar adds in one kernel.  Ways out at the source level: `add_np` / `keep_scalar`
-      (common.h) on one of the two scalar operations the compiler paired, or -packed-fp32-ops for a whole file whose kernels
-      do not need packed math (build.py: the head's files).
+      source register pair.  No kernel of the library may contain one.  v_pk_mov_b32 with op_sel is banned with them although
+      the stand-alone reproducer (scripts/probes/probe_pk_crosshalf.hip) clears it - 0 wrong results in 2.4e12 executions where
+      the arithmetic form had 18 events - because the ban costs three scalar adds in one kernel and "the same operand selection"
+      is too close to argue about.
   R2  (reported)     the mirror form, op_sel_hi with a 0 on a VGPR pair (HIGH result half from a LOW source half: the
       scalar-broadcast form the compiler uses everywhere).  Not observed to fail - the GEMM epilogues are full of it and
       every bit-exactness test and soak of rounds 1-4 ran through them, and the probe's `pk_bcast` variant (that form in the

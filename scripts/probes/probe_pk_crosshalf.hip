@@ -1,0 +1,131 @@
+// Stand-alone reproducer for DESIGN.md section 4 ("The co-residency corruption, root-caused"): does
+//     v_pk_add_f32 vD[0:1], vA[0:1], vB[0:1] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]      ; {A.lo - B.hi, A.hi - B.lo}
+// compute its LOW half wrong beside waves that keep the matrix pipe busy with v_mfma_f32_32x32x16_f16?  A victim kernel executes
+// that instruction (inline asm, nothing for the compiler to rearrange) in a loop on per-lane operands and compares both halves
+// with scalar v_sub_f32 results; a neighbour kernel (the library's cbas_debug_mfma_neighbor loop) runs on another stream, two
+// waves per SIMD on every CU.  Forms: 0 the cross-half form above, 1 the plain form (operands moved into place first: control),
+// 2 the cross-half selection done by v_pk_mov_b32 and a plain v_pk_add_f32.  Prints one JSON line per form: instruction
+// executions (per wave), wrong low / high halves by 16-lane group, and the first wrong sample.
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/probes/bin/probe_pk_crosshalf scripts/probes/probe_pk_crosshalf.hip
+//   scripts/probes/bin/probe_pk_crosshalf [seconds per form] [with_neighbour 0|1]
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(512) void mfma_neighbor_kernel(int iters, float* sink) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    f16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            unsigned x = (t * 64 + i * 8 + e) * 2654435761u; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            a[i][e] = (f16)(((int)(x & 0xffff) - 32768) * (1.0f / 32768.0f));
+            b[i][e] = (f16)(((int)(x >> 16) - 32768) * (1.0f / 32768.0f));
+        }
+    f16v c[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) c[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + r) & 3], b[(i * 2 + r) & 3], c[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) s += c[i][e];
+    if (s == 123.456f) sink[t] = s;
+}
+
+struct Counts { unsigned long long lo_wrong[4], hi_wrong[4], execs; float sample[8]; int have_sample; };
+
+template <int FORM>
+__global__ __launch_bounds__(256) void victim_kernel(int iters, Counts* out) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned x = t * 2654435761u + 12345u;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return ((int)(x & 0xffffff) - 0x800000) * (1.0f / 0x100000); };
+    // operands live in register PAIRS for the whole loop and are updated by packed ops without operand selection, so that the
+    // only cross-half selection in the loop is the instruction under test (building {b, a} from scalars each round made the
+    // compiler emit v_pk_mov_b32 ... op_sel:[1,0] in every form, the control included)
+    float a = rnd(), b = rnd(), c = rnd();
+    f32x2 A = {b, a}, B = {b, c}, Bs = {c, b};                 // A = v[10:11] of the kernel, B = v[8:9]; Bs = B's halves in place for the control
+    const f32x2 mA = {1.001f, 0.999f}, cA = {-0.11f, 0.37f}, mB = {1.001f, 0.998f}, cB = {-0.11f, 0.23f};
+    const f32x2 mS = {0.998f, 1.001f}, cS = {0.23f, -0.11f};
+    unsigned lo_bad = 0, hi_bad = 0;
+    float s_lo = 0, s_hi = 0, s_a = 0, s_b = 0, s_c = 0, g_lo = 0, g_hi = 0;
+    for (int it = 0; it < iters; ++it) {
+        f32x2 R;
+        float want_lo, want_hi;
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]));       // b - c
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]));       // a - b
+        if (FORM == 0) {
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(A), "v"(B));
+        } else if (FORM == 1) {
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(A), "v"(Bs));
+        } else {
+            f32x2 Bm;
+            asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]\n\ts_nop 0" : "=v"(Bm) : "v"(B));      // {B.hi, B.lo} = {c, b}
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(A), "v"(Bm));
+        }
+        asm volatile("s_nop 0");
+        const bool bl = __float_as_uint(R[0]) != __float_as_uint(want_lo), bh = __float_as_uint(R[1]) != __float_as_uint(want_hi);
+        if (bl || bh) {
+            if (!lo_bad && !hi_bad) { s_lo = want_lo; s_hi = want_hi; s_a = A[1]; s_b = A[0]; s_c = B[1]; g_lo = R[0]; g_hi = R[1]; }
+            lo_bad += bl; hi_bad += bh;
+        }
+        A = A * mA + cA; B = B * mB + cB; Bs = Bs * mS + cS;           // new operands every round (b identical in all three pairs)
+        if (!(fabsf(A[0]) < 64.f && fabsf(A[1]) < 64.f && fabsf(B[1]) < 64.f)) {
+            a = rnd(); b = rnd(); c = rnd();
+            A = f32x2{b, a}; B = f32x2{b, c}; Bs = f32x2{c, b};
+        }
+    }
+    const int grp = (threadIdx.x & 63) >> 4;
+    if (lo_bad) atomicAdd(&out->lo_wrong[grp], (unsigned long long)lo_bad);
+    if (hi_bad) atomicAdd(&out->hi_wrong[grp], (unsigned long long)hi_bad);
+    if ((lo_bad || hi_bad) && atomicCAS(&out->have_sample, 0, 1) == 0) {
+        out->sample[0] = s_a; out->sample[1] = s_b; out->sample[2] = s_c; out->sample[3] = s_lo; out->sample[4] = g_lo;
+        out->sample[5] = s_hi; out->sample[6] = g_hi; out->sample[7] = (float)(threadIdx.x & 63);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out->execs, (unsigned long long)iters);
+}
+
+int main(int argc, char** argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 20.0;
+    const int with_nb = argc > 2 ? atoi(argv[2]) : 1;
+    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    hipStream_t sa, sb; (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    float* sink; (void)hipMalloc(&sink, (size_t)cus * 512 * 4);
+    Counts* dc; (void)hipMalloc(&dc, sizeof(Counts));
+    const char* names[3] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add"};
+    for (int form = 0; form < 3; ++form) {
+        (void)hipMemset(dc, 0, sizeof(Counts));
+        (void)hipDeviceSynchronize();
+        const auto t0 = std::chrono::steady_clock::now();
+        long launches = 0;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            if (with_nb) hipLaunchKernelGGL(mfma_neighbor_kernel, dim3(cus), dim3(512), 0, sa, 20000, sink);
+            for (int k = 0; k < 8; ++k) {
+                if (form == 0) hipLaunchKernelGGL(victim_kernel<0>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 1) hipLaunchKernelGGL(victim_kernel<1>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 2) hipLaunchKernelGGL(victim_kernel<2>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                ++launches;
+            }
+            (void)hipStreamSynchronize(sb);
+            (void)hipStreamSynchronize(sa);
+        }
+        Counts h; (void)hipMemcpy(&h, dc, sizeof(h), hipMemcpyDeviceToHost);
+        printf("{\"form\": \"%s\", \"neighbour\": %d, \"victim_launches\": %ld, \"wave_executions\": %llu, \"low_half_wrong_by_lane_group\": [%llu, %llu, %llu, %llu], "
+               "\"high_half_wrong_by_lane_group\": [%llu, %llu, %llu, %llu]", names[form], with_nb, launches, h.execs,
+               h.lo_wrong[0], h.lo_wrong[1], h.lo_wrong[2], h.lo_wrong[3], h.hi_wrong[0], h.hi_wrong[1], h.hi_wrong[2], h.hi_wrong[3]);
+        if (h.have_sample)
+            printf(", \"first_wrong\": {\"a\": %.9g, \"b\": %.9g, \"c\": %.9g, \"low_wanted_b_minus_c\": %.9g, \"low_got\": %.9g, \"high_wanted_a_minus_b\": %.9g, \"high_got\": %.9g, \"lane\": %d}",
+                   h.sample[0], h.sample[1], h.sample[2], h.sample[3], h.sample[4], h.sample[5], h.sample[6], (int)h.sample[7]);
+        printf("}\n");
+        fflush(stdout);
+    }
+    return 0;
+}
