@@ -7,7 +7,9 @@
 // 2 the cross-half selection done by v_pk_mov_b32 and a plain v_pk_add_f32.  Prints one JSON line per form: instruction
 // executions (per wave), wrong low / high halves by 16-lane group, and the first wrong sample.
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/probes/bin/probe_pk_crosshalf scripts/probes/probe_pk_crosshalf.hip
-//   scripts/probes/bin/probe_pk_crosshalf [seconds per form] [with_neighbour 0|1]
+//   scripts/probes/bin/probe_pk_crosshalf [seconds per form] [neighbour: 0 none | 1 v_mfma_f32_32x32x16_f16 | 2 v_mfma_f32_16x16x32_f16]
+//   PK_FORMS=3,4,5,6,7 selects further forms: the low-from-high selection without negation / on a multiply / on an FMA, and the
+//   MIRROR (high from low: the scalar-broadcast form the compiler uses throughout the GEMM epilogues) on an add and on an FMA
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -16,6 +18,30 @@ typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// the same with v_mfma_f32_16x16x32_f16 (the instruction of the library's own fp16 GEMMs and attention kernels)
+__global__ __launch_bounds__(512) void mfma16_neighbor_kernel(int iters, float* sink) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    f16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            unsigned x = (t * 64 + i * 8 + e) * 2654435761u; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            a[i][e] = (f16)(((int)(x & 0xffff) - 32768) * (1.0f / 32768.0f));
+            b[i][e] = (f16)(((int)(x >> 16) - 32768) * (1.0f / 32768.0f));
+        }
+    f32x4v c[8];
+    for (int i = 0; i < 8; ++i) c[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + r) & 3], b[(i * 2 + r) & 3], c[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][3];
+    if (s == 123.456f) sink[t] = s;
+}
 
 __global__ __launch_bounds__(512) void mfma_neighbor_kernel(int iters, float* sink) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,16 +86,38 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, Counts* out) {
     for (int it = 0; it < iters; ++it) {
         f32x2 R;
         float want_lo, want_hi;
-        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]));       // b - c
-        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]));       // a - b
+        if (FORM <= 2) {
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]));       // b - c
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]));       // a - b
+        }
         if (FORM == 0) {
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(A), "v"(B));
         } else if (FORM == 1) {
             asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(A), "v"(Bs));
-        } else {
+        } else if (FORM == 2) {
             f32x2 Bm;
             asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]\n\ts_nop 0" : "=v"(Bm) : "v"(B));      // {B.hi, B.lo} = {c, b}
             asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(A), "v"(Bm));
+        } else if (FORM == 3) {                                 // low half from src1's HIGH half, no negation: {A.lo + B.hi, A.hi + B.hi}
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[1]));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(R) : "v"(A), "v"(B));
+        } else if (FORM == 4) {                                 // the same selection on a multiply
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[1]));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(R) : "v"(A), "v"(B));
+        } else if (FORM == 5) {                                 // ... on a fused multiply-add (src1's high half for both halves)
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]), "v"(Bs[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_hi) : "v"(A[1]), "v"(B[1]), "v"(Bs[1]));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(R) : "v"(A), "v"(B), "v"(Bs));
+        } else if (FORM == 6) {                                 // the MIRROR: high half from src1's LOW half (the broadcast form): {A.lo + B.lo, A.hi + B.lo}
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[0]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(R) : "v"(A), "v"(B));
+        } else {                                                // the mirror on a fused multiply-add: the GEMM epilogues' form
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_lo) : "v"(A[0]), "v"(B[0]), "v"(Bs[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]), "v"(Bs[1]));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(R) : "v"(A), "v"(B), "v"(Bs));
         }
         asm volatile("s_nop 0");
         const bool bl = __float_as_uint(R[0]) != __float_as_uint(want_lo), bh = __float_as_uint(R[1]) != __float_as_uint(want_hi);
@@ -100,18 +148,30 @@ int main(int argc, char** argv) {
     hipStream_t sa, sb; (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
     float* sink; (void)hipMalloc(&sink, (size_t)cus * 512 * 4);
     Counts* dc; (void)hipMalloc(&dc, sizeof(Counts));
-    const char* names[3] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add"};
-    for (int form = 0; form < 3; ++form) {
+    const char* names[8] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add",
+                            "v_pk_add_f32 op_sel:[0,1] (low from src1.hi, no negation)", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
+                            "MIRROR v_pk_add_f32 op_sel_hi:[1,0] (high from src1.lo: broadcast)", "MIRROR v_pk_fma_f32 op_sel_hi:[1,0,1]"};
+    const char* forms_env = getenv("PK_FORMS");                         // e.g. PK_FORMS=3,4,5,6,7 ; default 0,1,2
+    bool want[8] = {!forms_env, !forms_env, !forms_env, false, false, false, false, false};
+    if (forms_env) for (const char* p = forms_env; *p; ++p) if (*p >= '0' && *p <= '7') want[*p - '0'] = true;
+    for (int form = 0; form < 8; ++form) {
+        if (!want[form]) continue;
         (void)hipMemset(dc, 0, sizeof(Counts));
         (void)hipDeviceSynchronize();
         const auto t0 = std::chrono::steady_clock::now();
         long launches = 0;
         while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
-            if (with_nb) hipLaunchKernelGGL(mfma_neighbor_kernel, dim3(cus), dim3(512), 0, sa, 20000, sink);
+            if (with_nb == 1) hipLaunchKernelGGL(mfma_neighbor_kernel, dim3(cus), dim3(512), 0, sa, 20000, sink);
+            if (with_nb == 2) hipLaunchKernelGGL(mfma16_neighbor_kernel, dim3(cus), dim3(512), 0, sa, 20000, sink);
             for (int k = 0; k < 8; ++k) {
                 if (form == 0) hipLaunchKernelGGL(victim_kernel<0>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 if (form == 1) hipLaunchKernelGGL(victim_kernel<1>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 if (form == 2) hipLaunchKernelGGL(victim_kernel<2>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 3) hipLaunchKernelGGL(victim_kernel<3>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 4) hipLaunchKernelGGL(victim_kernel<4>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 5) hipLaunchKernelGGL(victim_kernel<5>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 6) hipLaunchKernelGGL(victim_kernel<6>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 7) hipLaunchKernelGGL(victim_kernel<7>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 ++launches;
             }
             (void)hipStreamSynchronize(sb);
