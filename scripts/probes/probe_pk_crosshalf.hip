@@ -67,6 +67,25 @@ __global__ __launch_bounds__(512) void mfma_neighbor_kernel(int iters, float* si
     if (s == 123.456f) sink[t] = s;
 }
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int CTRL> static __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+// the wave sums of the library's LayerNorm kernels (csrc/common.h: wave_sum_dpp) and the __shfl_xor butterfly they replaced
+static __device__ __forceinline__ float wave_sum_dpp(float v) {
+    u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    v += dpp_f32<0x128>(v); v += dpp_f32<0x124>(v); v += dpp_f32<0x122>(v); v += dpp_f32<0x121>(v);
+    return v;
+}
+static __device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 struct Counts { unsigned long long lo_wrong[4], hi_wrong[4], execs; float sample[8]; int have_sample; };
 
 template <int FORM>
@@ -86,6 +105,10 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, Counts* out) {
     for (int it = 0; it < iters; ++it) {
         f32x2 R;
         float want_lo, want_hi;
+        if (FORM == 8) {                                        // not a packed op: the permlane-swap + DPP wave sum against the shuffle butterfly
+            want_lo = wave_sum_shfl(A[0]); want_hi = wave_sum_shfl(A[1]);
+            R[0] = wave_sum_dpp(A[0]); R[1] = wave_sum_dpp(A[1]);
+        } else
         if (FORM <= 2) {
             asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[1]));       // b - c
             asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]));       // a - b
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, Counts* out) {
             asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[0]));
             asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]));
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(R) : "v"(A), "v"(B));
-        } else {                                                // the mirror on a fused multiply-add: the GEMM epilogues' form
+        } else if (FORM == 7) {                                 // the mirror on a fused multiply-add: the GEMM epilogues' form
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_lo) : "v"(A[0]), "v"(B[0]), "v"(Bs[0]));
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_hi) : "v"(A[1]), "v"(B[0]), "v"(Bs[1]));
             asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(R) : "v"(A), "v"(B), "v"(Bs));
@@ -148,13 +171,14 @@ int main(int argc, char** argv) {
     hipStream_t sa, sb; (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
     float* sink; (void)hipMalloc(&sink, (size_t)cus * 512 * 4);
     Counts* dc; (void)hipMalloc(&dc, sizeof(Counts));
-    const char* names[8] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add",
+    const char* names[9] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add",
                             "v_pk_add_f32 op_sel:[0,1] (low from src1.hi, no negation)", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
-                            "MIRROR v_pk_add_f32 op_sel_hi:[1,0] (high from src1.lo: broadcast)", "MIRROR v_pk_fma_f32 op_sel_hi:[1,0,1]"};
+                            "MIRROR v_pk_add_f32 op_sel_hi:[1,0] (high from src1.lo: broadcast)", "MIRROR v_pk_fma_f32 op_sel_hi:[1,0,1]",
+                            "wave sum by v_permlane32/16_swap + v_add_f32_dpp row_ror (LayerNorm, r5) against the __shfl_xor butterfly"};
     const char* forms_env = getenv("PK_FORMS");                         // e.g. PK_FORMS=3,4,5,6,7 ; default 0,1,2
-    bool want[8] = {!forms_env, !forms_env, !forms_env, false, false, false, false, false};
-    if (forms_env) for (const char* p = forms_env; *p; ++p) if (*p >= '0' && *p <= '7') want[*p - '0'] = true;
-    for (int form = 0; form < 8; ++form) {
+    bool want[9] = {!forms_env, !forms_env, !forms_env, false, false, false, false, false, false};
+    if (forms_env) for (const char* p = forms_env; *p; ++p) if (*p >= '0' && *p <= '8') want[*p - '0'] = true;
+    for (int form = 0; form < 9; ++form) {
         if (!want[form]) continue;
         (void)hipMemset(dc, 0, sizeof(Counts));
         (void)hipDeviceSynchronize();
@@ -172,6 +196,7 @@ int main(int argc, char** argv) {
                 if (form == 5) hipLaunchKernelGGL(victim_kernel<5>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 if (form == 6) hipLaunchKernelGGL(victim_kernel<6>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 if (form == 7) hipLaunchKernelGGL(victim_kernel<7>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 8) hipLaunchKernelGGL(victim_kernel<8>, dim3(cus * 2), dim3(256), 0, sb, 4000, dc);
                 ++launches;
             }
             (void)hipStreamSynchronize(sb);
