@@ -693,9 +693,32 @@ __device__ __forceinline__ float exp_raw(float d) {
 #ifndef CBAS_ATTN_ABLATE
 #define CBAS_ATTN_ABLATE 0
 #endif
-__global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __restrict__ qkv, const float* __restrict__ q_cls,
-                                                                 float* __restrict__ out, int T, int D, int n_heads, int qblocks,
-                                                                 float out_scale, int npairs, int total_items) {
+// Wave priority raised (s_setprio 1) around: 1 the S MFMAs, 2 the P.V MFMAs, 4 the softmax, 8 the K / V staging - so that the
+// waves of a SIMD, which leave every barrier in the same phase, fall out of step.  Default 5 (r5, scripts/attn_variants.sh,
+// profiles/r05_attention_priority_ab.json): the softmax - the VALU phase, the kernel's largest pipe demand - is what gains
+// (3-4 us of 56-62 per layer on three boxes, rows identical); priority on the MFMA clusters alone does nothing.  The STEP
+// does not move with it: at precision 4 the board is at its power limit and the time comes back as clock.
+#ifndef CBAS_ATTN_PRIO
+#define CBAS_ATTN_PRIO 5
+#endif
+#ifndef CBAS_ATTN_PRIO_LEVEL
+#define CBAS_ATTN_PRIO_LEVEL 1
+#endif
+#define ATTN_PRIO_ON(bit)  do { if (CBAS_ATTN_PRIO & (bit)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(CBAS_ATTN_PRIO_LEVEL); } } while (0)
+#define ATTN_PRIO_OFF(bit) do { if (CBAS_ATTN_PRIO & (bit)) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } } while (0)
+// Experiment switch: -DCBAS_ATTN_WIDE=1 = ONE workgroup per (frame, head) with a wave per query tile (up to 16 waves; T <= 256),
+// K / V staged once per pair instead of once per query block; one such workgroup per CU.  0 (default): measured 59.6 against
+// 61.3 us alone, 60.0 against 57.3 with the priorities (profiles/r05_attention_priority_ab.json).
+#ifndef CBAS_ATTN_WIDE
+#define CBAS_ATTN_WIDE 0
+#endif
+#if CBAS_ATTN_WIDE
+__global__ __launch_bounds__(1024, 1) void attention_split_kernel(
+#else
+__global__ __launch_bounds__(512, 2) void attention_split_kernel(
+#endif
+    const float* __restrict__ qkv, const float* __restrict__ q_cls, float* __restrict__ out, int T, int D, int n_heads, int qblocks,
+    float out_scale, int npairs, int total_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [buf][K_hi | K_lo | V_hi | V_lo][64 keys][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
@@ -776,6 +799,7 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         const int left = T - kb * AKB;
         const int nkt = FULL ? 4 : (left + 15) >> 4;              // key tiles with at least one real key (wave-uniform)
         f32x4 s[4];
+        ATTN_PRIO_ON(1);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             if (!FULL && kt >= nkt) { s[kt] = f32x4{NEG, NEG, NEG, NEG}; continue; }
@@ -794,6 +818,8 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
 #endif
             s[kt] = acc;
         }
+        ATTN_PRIO_OFF(1);
+        ATTN_PRIO_ON(4);
         if (!FULL) {                                              // only a partial block can hold keys past T
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -836,6 +862,8 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
         mrun = mnew;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+        ATTN_PRIO_OFF(4);
+        ATTN_PRIO_ON(2);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             if (!FULL && 2 * s2 >= nkt) continue;                 // both tiles of the group are padding
@@ -863,12 +891,15 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(const float* __
 #endif
             }
         }
+        ATTN_PRIO_OFF(2);
     };
     for (int kb = 0; kb < nkb; ++kb) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
         __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
+        ATTN_PRIO_ON(8);
         if (kb + 1 < nkb) stage((gb + kb + 1) & 1, pair, kb + 1);
         else if (following < total_items) stage((gb + kb + 1) & 1, item_pair(following), 0);      // the next item's first block
+        ATTN_PRIO_OFF(8);
         if (active) {
             // a full block (64 real keys: every block but the last) runs without the per-tile tests, so that its four key
             // tiles are four independent MFMA chains in one basic block; same operations per query either way
@@ -991,6 +1022,12 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
         if (waste < best) { best = waste; nw = w; }
     }
     if (q_cls) nw = 4;
+#if CBAS_ATTN_WIDE
+    const bool wide = split_scale > 0.f && !q_cls && ntiles <= 16;
+    if (wide) nw = ntiles;
+#else
+    const bool wide = false;
+#endif
     const int qblocks = (ntiles + nw - 1) / nw;
     const int npairs = n * n_heads;
     const int64_t grid = (int64_t)((npairs + 7) / 8) * 8 * qblocks;        // whole groups of 8 pairs: see the kernels' workgroup map
@@ -1012,7 +1049,7 @@ int launch_attention_f32(const float* qkv, const float* q_cls, float* out, int n
         if (persist) {
             static int cus = 0;
             if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
-            const int64_t cap = (int64_t)(2 * cus) / 8 * 8;
+            const int64_t cap = (int64_t)((wide ? 1 : 2) * cus) / 8 * 8;
             if (cap > 0 && launch > cap) launch = cap;
         }
         hipLaunchKernelGGL(attention_split_kernel, dim3((unsigned)launch), dim3(nw * 64), lds2, stream, qkv, q_cls, out, T, D, n_heads,
