@@ -27,7 +27,7 @@ for round in $(seq 1 ${ROUNDS:-2}); do
     python bench.py --precision 4 --no-label-exact --no-cpu-baseline --no-host-path --files 0 --steps 40 --warmup 3 > $OUT/bench_v${i}_r$round.json 2>> $OUT/bench.err
     python3 -c "
 import json; d=json.load(open('$OUT/bench_v${i}_r$round.json')); k=d['roofline']['by_kernel']; g=d.get('gates') or {}
-print(json.dumps({'variant': '$v', 'round': $round, 'attention_avg_us': k['attention']['avg_us'], 'value': d['value'], 'cls_rel_err_max': g.get('cls_rel_err_max'), 'e2e_long_label_mismatches': (g.get('e2e_long') or {}).get('label_mismatches')}))" | tee -a $OUT/summary.jsonl
+print(json.dumps({'variant': '$v', 'round': $round, 'attention_avg_us': k['attention']['avg_us'], 'layernorm_avg_us': k['layernorm']['avg_us'], 'value': d['value'], 'cls_rel_err_max': g.get('cls_rel_err_max'), 'e2e_long_label_mismatches': (g.get('e2e_long') or {}).get('label_mismatches')}))" | tee -a $OUT/summary.jsonl
     i=$((i+1))
   done
 done
