@@ -229,7 +229,8 @@ static int dispatch_gemm(GemmEpilogue epi, const GemmParams& p, int tile, hipStr
 int launch_gemm(GemmEpilogue epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     static const int gm_env = [] { const char* e = getenv("CBAS_GEMM_GM"); return e ? atoi(e) : 0; }();
-    if (!p.group_m) p.group_m = gm_env > 0 ? gm_env : 1;
+    static const int gmw_env = [] { const char* e = getenv("CBAS_GEMM_GM_WIDE"); return e ? atoi(e) : 0; }();      // N >= 2048 only (experiment)
+    if (!p.group_m) p.group_m = gm_env > 0 ? gm_env : (gmw_env > 0 && p.N / 256 >= 8 ? gmw_env : 1);
     if (!p.lda) p.lda = p.K;
     if (p.N % 128 || p.K % BK || p.M > p.M_pad || p.M <= 0) return -1;
     if (epi_base(epi) == EPI_QKV && (p.D % 64 || p.N % p.D || p.sec0 < 0 || p.N / p.D + p.sec0 > 3)) return -1;

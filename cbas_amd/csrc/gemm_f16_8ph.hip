@@ -692,6 +692,16 @@ int launch_gemm_split_pp(GemmEpilogue epi, const Gemm32VitParams& sp_in, hipStre
     p.N = sp.N;
     p.K = sp.K;
     p.stamps = g_split_stamps;
+    // Raster (r5, scripts/gemm_gm_ab.sh, profiles/r05_gemm_raster_ab.json): where a row of tiles is long (N >= 2048: q|k|v, up) groups
+    // of 6 row panels, row-fastest inside a group, so that the ~32 tiles an XCD runs at a time form a 6 x 5 block and share
+    // operand panels in its L2 - `up` fetches 20 % less from the fabric; the N = 768 GEMMs (three column tiles per row panel: a
+    // compact block already) fetch 18-24 % MORE when grouped and keep N-fastest.  +1.0 % frames/s at precision 4 against
+    // N-fastest everywhere, rows identical.  The fp16 kernels lose 0.5 % with groups and keep N-fastest: operands here are twice
+    // the bytes and the step is bound by energy - fabric traffic saved comes back as clock.
+    // CBAS_GEMM_GM=<n> forces n everywhere (1 = N-fastest), CBAS_GEMM_GM_WIDE=<n> the wide shapes only.
+    static const int gm_env = [] { const char* e = getenv("CBAS_GEMM_GM"); return e ? atoi(e) : 0; }();
+    static const int gmw_env = [] { const char* e = getenv("CBAS_GEMM_GM_WIDE"); return e ? atoi(e) : 0; }();      // the wide shapes only
+    p.group_m = gm_env > 0 ? gm_env : (p.N / 256 >= 8 ? (gmw_env > 0 ? gmw_env : 6) : 1);
     switch (epi) {
         case EPI_PATCH: return launch_split_pp_epi<EPI_PATCH>(p, sp, stream);
         case EPI_QKV:   return launch_split_pp_epi<EPI_QKV>(p, sp, stream);
