@@ -689,7 +689,8 @@ __device__ __forceinline__ float exp_raw(float d) {
 // Measurement aid (scripts/attn_ablate.sh): -DCBAS_ATTN_ABLATE=<bits> compiles parts of a key block OUT - the
 // results are then garbage, the point is what each part costs: 1 the softmax's exponentials and hi / lo split, 2 the P.V MFMAs
 // and V's LDS reads, 4 V's LDS reads only (the MFMAs run on constant fragments), 8 the S MFMAs and K's LDS reads, 16 the K / V
-// stream itself (no LDS-DMA; barriers stay), 32 the final stores.  0 (default).
+// stream itself (no LDS-DMA; barriers stay), 32 the final stores, 64 HALF of the K and V fragment reads (what a form with two query
+// tiles per wave would save).  0 (default).
 #ifndef CBAS_ATTN_ABLATE
 #define CBAS_ATTN_ABLATE 0
 #endif
@@ -799,6 +800,9 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(
         const int left = T - kb * AKB;
         const int nkt = FULL ? 4 : (left + 15) >> 4;              // key tiles with at least one real key (wave-uniform)
         f32x4 s[4];
+#if CBAS_ATTN_ABLATE & 64
+        f16x8 kkeep[2][2];
+#endif
         ATTN_PRIO_ON(1);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -809,8 +813,19 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(
 #else
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
+#if CBAS_ATTN_ABLATE & 64
+                // half the K fragment reads: an odd tile re-uses the even tile's fragments (through an opaque copy, so that its
+                // MFMAs are not folded into the even tile's)
+                if (!(kt & 1)) {
+                    kkeep[h2][0] = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
+                    kkeep[h2][1] = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+                }
+                f16x8 kh = kkeep[h2][0], kl = kkeep[h2][1];
+                if (kt & 1) asm volatile("" : "+v"(kh), "+v"(kl));
+#else
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
                 const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+#endif
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
@@ -870,7 +885,11 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(
             const int krow = 32 * s2 + 4 * g + (li >> 2);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
+#if CBAS_ATTN_ABLATE & 64
+                const int col = 16 * (dt & ~1) + 4 * (li & 3);        // half the V fragment reads
+#else
                 const int col = 16 * dt + 4 * (li & 3);
+#endif
                 union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
 #if CBAS_ATTN_ABLATE & 2
                 o[dt][0] += (float)ph[s2][0] + (float)pl[s2][1];               // keeps P alive; no reads, no MFMAs
