@@ -8,7 +8,7 @@
 // executions (per wave), wrong low / high halves by 16-lane group, and the first wrong sample.
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/probes/bin/probe_pk_crosshalf scripts/probes/probe_pk_crosshalf.hip
 //   scripts/probes/bin/probe_pk_crosshalf [seconds per form] [neighbour: 0 none | 1 v_mfma_f32_32x32x16_f16 | 2 v_mfma_f32_16x16x32_f16]
-//   PK_FORMS=3,4,5,6,7 (digits; 8 = the DPP wave sum, 9 = the mirror multiply, a = SDWA half reads) selects further forms: the low-from-high selection without negation / on a multiply / on an FMA, and the
+//   PK_FORMS=3,4,5,6,7 (digits; 8 = the DPP wave sum, 9 = the mirror multiply, a = SDWA half reads, b / c = the selection on src0 / on an FMA's addend) selects further forms: the low-from-high selection without negation / on a multiply / on an FMA, and the
 //   MIRROR (high from low: the scalar-broadcast form the compiler uses throughout the GEMM epilogues) on an add and on an FMA
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -145,6 +145,14 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, Counts* out) {
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[0]), "v"(B[0]));
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[0]), "v"(B[1]));
             asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(R) : "v"(A), "v"(B));
+        } else if (FORM == 11) {                                // the selection on SRC0: low half from src0's high half: {A.hi + B.lo, A.hi + B.hi}
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_lo) : "v"(A[1]), "v"(B[0]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want_hi) : "v"(A[1]), "v"(B[1]));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(R) : "v"(A), "v"(B));
+        } else if (FORM == 12) {                                // the selection on an FMA's ADDEND (src2): {A.lo B.lo + C.hi, A.hi B.hi + C.hi}
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_lo) : "v"(A[0]), "v"(B[0]), "v"(Bs[1]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want_hi) : "v"(A[1]), "v"(B[1]), "v"(Bs[1]));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(R) : "v"(A), "v"(B), "v"(Bs));
         } else if (FORM == 10) {                                // half selection INSIDE a register: SDWA reads of the high / low fp16 of a dword (412 sites)
             unsigned pk, hi16;
             asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(A[0]), "v"(B[1]));      // {f16(A.lo), f16(B.hi)}
@@ -183,19 +191,21 @@ int main(int argc, char** argv) {
     hipStream_t sa, sb; (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
     float* sink; (void)hipMalloc(&sink, (size_t)cus * 512 * 4);
     Counts* dc; (void)hipMalloc(&dc, sizeof(Counts));
-    const char* names[11] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add",
+    const char* names[13] = {"cross-half op_sel", "plain (control)", "v_pk_mov_b32 cross-half + plain add",
                             "v_pk_add_f32 op_sel:[0,1] (low from src1.hi, no negation)", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
                             "MIRROR v_pk_add_f32 op_sel_hi:[1,0] (high from src1.lo: broadcast)", "MIRROR v_pk_fma_f32 op_sel_hi:[1,0,1]",
                             "wave sum by v_permlane32/16_swap + v_add_f32_dpp row_ror (LayerNorm, r5) against the __shfl_xor butterfly",
                             "MIRROR v_pk_mul_f32 op_sel_hi:[0,1]",
-                            "v_cvt_f32_f16_sdwa src0_sel:WORD_1 / WORD_0 (half selection inside a register)"};
+                            "v_cvt_f32_f16_sdwa src0_sel:WORD_1 / WORD_0 (half selection inside a register)",
+                            "v_pk_add_f32 op_sel:[1,0] (low half from SRC0's high half)",
+                            "v_pk_fma_f32 op_sel:[0,0,1] (low half's ADDEND from src2's high half)"};
     const char* forms_env = getenv("PK_FORMS");                         // e.g. PK_FORMS=3,4,5,6,7 ; default 0,1,2
-    bool want[11] = {!forms_env, !forms_env, !forms_env, false, false, false, false, false, false, false, false};
-    if (forms_env) for (const char* p = forms_env; *p; ++p) {                  // digits 0-9, 'a' = 10
+    bool want[13] = {!forms_env, !forms_env, !forms_env, false, false, false, false, false, false, false, false, false, false};
+    if (forms_env) for (const char* p = forms_env; *p; ++p) {                  // digits 0-9, 'a' = 10, 'b' = 11, 'c' = 12
         if (*p >= '0' && *p <= '9') want[*p - '0'] = true;
-        if (*p == 'a') want[10] = true;
+        if (*p >= 'a' && *p <= 'c') want[10 + *p - 'a'] = true;
     }
-    for (int form = 0; form < 11; ++form) {
+    for (int form = 0; form < 13; ++form) {
         if (!want[form]) continue;
         (void)hipMemset(dc, 0, sizeof(Counts));
         (void)hipDeviceSynchronize();
@@ -216,6 +226,8 @@ int main(int argc, char** argv) {
                 if (form == 8) hipLaunchKernelGGL(victim_kernel<8>, dim3(cus * 2), dim3(256), 0, sb, 4000, dc);
                 if (form == 9) hipLaunchKernelGGL(victim_kernel<9>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 if (form == 10) hipLaunchKernelGGL(victim_kernel<10>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 11) hipLaunchKernelGGL(victim_kernel<11>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
+                if (form == 12) hipLaunchKernelGGL(victim_kernel<12>, dim3(cus * 2), dim3(256), 0, sb, 20000, dc);
                 ++launches;
             }
             (void)hipStreamSynchronize(sb);
