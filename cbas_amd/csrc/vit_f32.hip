@@ -764,188 +764,185 @@ __global__ __launch_bounds__(512, 2) void attention_split_kernel(
     int gb = 0;                                                        // blocks consumed so far: ring slot = gb & 1
     if (item < total_items) stage(0, item_pair(item), 0);
     for (; item < total_items;) {
-    const int following = next_item(item + gridDim.x);
-    const int xcd_k = item >> 3;
-    const int pair = item_pair(item), qb = xcd_k % qblocks;
-    const int b = pair / n_heads, hd = pair - b * n_heads;
-    const char* qbase = reinterpret_cast<const char*>(qkv) + (size_t)b * T * ldb + (size_t)hd * 256;
-    const int nq = q_cls ? 1 : T;
-    const int qt = qb * nwaves + wave;
-    const bool active = qt * 16 < nq;                                  // wave-uniform
-    const int q = qt * 16 + li;
-    const int qrow = q < nq ? q : nq - 1;
-    const char* qsrc = q_cls ? reinterpret_cast<const char*>(q_cls) + (size_t)b * D * 4 + (size_t)hd * 256 : qbase + (size_t)qrow * ldb;
-    f16x8 qh[2], ql[2];
+        const int following = next_item(item + gridDim.x);
+        const int xcd_k = item >> 3;
+        const int pair = item_pair(item), qb = xcd_k % qblocks;
+        const int b = pair / n_heads, hd = pair - b * n_heads;
+        const char* qbase = reinterpret_cast<const char*>(qkv) + (size_t)b * T * ldb + (size_t)hd * 256;
+        const int nq = q_cls ? 1 : T;
+        const int qt = qb * nwaves + wave;
+        const bool active = qt * 16 < nq;                                  // wave-uniform
+        const int q = qt * 16 + li;
+        const int qrow = q < nq ? q : nq - 1;
+        const char* qsrc = q_cls ? reinterpret_cast<const char*>(q_cls) + (size_t)b * D * 4 + (size_t)hd * 256 : qbase + (size_t)qrow * ldb;
+        f16x8 qh[2], ql[2];
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {                                   // k-half h2: d in [32 h2, 32 h2 + 32): chunk 4 h2 + g
-        qh[h2] = *reinterpret_cast<const f16x8*>(qsrc + (4 * h2 + g) * 16);
-        ql[h2] = *reinterpret_cast<const f16x8*>(qsrc + 128 + (4 * h2 + g) * 16);
-    }
-
-
-    // scores stay in the accumulator's units (x ATT_QS ATT_KS: max and differences scale exactly); the factor is undone
-    // inside the exponential's constant.  Masked scores are a large finite negative, not -inf: exp_raw needs no clamp.
-    constexpr float NEG = -1.0e30f;
-    float mrun = NEG, lrun = 0.f;
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto block = [&](int kb, auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
-        const char* Kh = smem + ((gb + kb) & 1) * 4 * SIMG;
-        const char* Kl = Kh + SIMG;
-        const char* Vh = Kl + SIMG;
-        const char* Vl = Vh + SIMG;
-        const int left = T - kb * AKB;
-        const int nkt = FULL ? 4 : (left + 15) >> 4;              // key tiles with at least one real key (wave-uniform)
-        f32x4 s[4];
-#if CBAS_ATTN_ABLATE & 64
-        f16x8 kkeep[2][2];
-#endif
-        ATTN_PRIO_ON(1);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            if (!FULL && kt >= nkt) { s[kt] = f32x4{NEG, NEG, NEG, NEG}; continue; }
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#if CBAS_ATTN_ABLATE & 8
-            acc = f32x4{(float)(kt + li), (float)g, (float)(kb & 3), 1.0f};
-#else
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-#if CBAS_ATTN_ABLATE & 64
-                // half the K fragment reads: an odd tile re-uses the even tile's fragments (through an opaque copy, so that its
-                // MFMAs are not folded into the even tile's)
-                if (!(kt & 1)) {
-                    kkeep[h2][0] = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
-                    kkeep[h2][1] = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
-                }
-                f16x8 kh = kkeep[h2][0], kl = kkeep[h2][1];
-                if (kt & 1) asm volatile("" : "+v"(kh), "+v"(kl));
-#else
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
-#endif
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
-            }
-#endif
-            s[kt] = acc;
+        for (int h2 = 0; h2 < 2; ++h2) {                                   // k-half h2: d in [32 h2, 32 h2 + 32): chunk 4 h2 + g
+            qh[h2] = *reinterpret_cast<const f16x8*>(qsrc + (4 * h2 + g) * 16);
+            ql[h2] = *reinterpret_cast<const f16x8*>(qsrc + 128 + (4 * h2 + g) * 16);
         }
-        ATTN_PRIO_OFF(1);
-        ATTN_PRIO_ON(4);
-        if (!FULL) {                                              // only a partial block can hold keys past T
+
+        // scores stay in the accumulator's units (x ATT_QS ATT_KS: max and differences scale exactly); the factor is undone
+        // inside the exponential's constant.  Masked scores are a large finite negative, not -inf: exp_raw needs no clamp.
+        constexpr float NEG = -1.0e30f;
+        float mrun = NEG, lrun = 0.f;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        auto block = [&](int kb, auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const char* Kh = smem + ((gb + kb) & 1) * 4 * SIMG;
+            const char* Kl = Kh + SIMG;
+            const char* Vh = Kl + SIMG;
+            const char* Vl = Vh + SIMG;
+            const int left = T - kb * AKB;
+            const int nkt = FULL ? 4 : (left + 15) >> 4;              // key tiles with at least one real key (wave-uniform)
+            f32x4 s[4];
+#if CBAS_ATTN_ABLATE & 64
+            f16x8 kkeep[2][2];
+#endif
+            ATTN_PRIO_ON(1);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (!FULL && kt >= nkt) { s[kt] = f32x4{NEG, NEG, NEG, NEG}; continue; }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#if CBAS_ATTN_ABLATE & 8
+                acc = f32x4{(float)(kt + li), (float)g, (float)(kb & 3), 1.0f};
+#else
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#if CBAS_ATTN_ABLATE & 64
+                    // half the K fragment reads: an odd tile re-uses the even tile's fragments (through an opaque copy, so that its
+                    // MFMAs are not folded into the even tile's)
+                    if (!(kt & 1)) {
+                        kkeep[h2][0] = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
+                        kkeep[h2][1] = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+                    }
+                    f16x8 kh = kkeep[h2][0], kl = kkeep[h2][1];
+                    if (kt & 1) asm volatile("" : "+v"(kh), "+v"(kl));
+#else
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + sk_off(kt * 16 + li, 4 * h2 + g));
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + sk_off(kt * 16 + li, 4 * h2 + g));
+#endif
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[h2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[h2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[h2], acc, 0, 0, 0);
+                }
+#endif
+                s[kt] = acc;
+            }
+            ATTN_PRIO_OFF(1);
+            ATTN_PRIO_ON(4);
+            if (!FULL) {                                              // only a partial block can hold keys past T
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = NEG;
+            }
+            float bm = NEG;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kb * AKB + kt * 16 + 4 * g + r >= T) s[kt][r] = NEG;
-        }
-        float bm = NEG;
+                for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
+            bm = xor16_max(bm);
+            bm = xor32_max(bm);
+            const float mnew = fmaxf(mrun, bm);
+            const float alpha = exp_raw(mrun - mnew);
+            float psum = 0.f;
+            f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int grp = 0; grp < 2; ++grp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bm = fmaxf(bm, s[kt][r]);
-        bm = xor16_max(bm);
-        bm = xor32_max(bm);
-        const float mnew = fmaxf(mrun, bm);
-        const float alpha = exp_raw(mrun - mnew);
-        float psum = 0.f;
-        f16x8 ph[2], pl[2];                                       // P^T of the two 32-key groups, hi and lo halves
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int grp = 0; grp < 2; ++grp)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r) {
 #if CBAS_ATTN_ABLATE & 1
-                    const f16 h = (f16)fminf(fabsf(s[2 * grp + u][r]), 1.0f);      // bounded (the range guard stays quiet), still depends on S
-                    ph[grp][4 * u + r] = h;
-                    pl[grp][4 * u + r] = h;
-                    psum += 1.0f;
+                        const f16 h = (f16)fminf(fabsf(s[2 * grp + u][r]), 1.0f);      // bounded (the range guard stays quiet), still depends on S
+                        ph[grp][4 * u + r] = h;
+                        pl[grp][4 * u + r] = h;
+                        psum += 1.0f;
 #else
-                    const float pv = exp_raw(s[2 * grp + u][r] - mnew);
-                    psum += pv;
-                    const float x = pv * ATT_PS;
-                    const f16 h = (f16)x;
-                    ph[grp][4 * u + r] = h;
-                    pl[grp][4 * u + r] = (f16)(x - (float)h);
+                        const float pv = exp_raw(s[2 * grp + u][r] - mnew);
+                        psum += pv;
+                        const float x = pv * ATT_PS;
+                        const f16 h = (f16)x;
+                        ph[grp][4 * u + r] = h;
+                        pl[grp][4 * u + r] = (f16)(x - (float)h);
 #endif
-                }
-        lrun = lrun * alpha + psum;
-        mrun = mnew;
+                    }
+            lrun = lrun * alpha + psum;
+            mrun = mnew;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-        ATTN_PRIO_OFF(4);
-        ATTN_PRIO_ON(2);
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            ATTN_PRIO_OFF(4);
+            ATTN_PRIO_ON(2);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            if (!FULL && 2 * s2 >= nkt) continue;                 // both tiles of the group are padding
-            const int krow = 32 * s2 + 4 * g + (li >> 2);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (!FULL && 2 * s2 >= nkt) continue;                 // both tiles of the group are padding
+                const int krow = 32 * s2 + 4 * g + (li >> 2);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < 4; ++dt) {
 #if CBAS_ATTN_ABLATE & 64
-                const int col = 16 * (dt & ~1) + 4 * (li & 3);        // half the V fragment reads
+                    const int col = 16 * (dt & ~1) + 4 * (li & 3);        // half the V fragment reads
 #else
-                const int col = 16 * dt + 4 * (li & 3);
+                    const int col = 16 * dt + 4 * (li & 3);
 #endif
-                union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
+                    union { struct { s16x4 a, b; } s; f16x8 v; } uh, ul;
 #if CBAS_ATTN_ABLATE & 2
-                o[dt][0] += (float)ph[s2][0] + (float)pl[s2][1];               // keeps P alive; no reads, no MFMAs
-                (void)krow; (void)col; (void)uh; (void)ul;
+                    o[dt][0] += (float)ph[s2][0] + (float)pl[s2][1];               // keeps P alive; no reads, no MFMAs
+                    (void)krow; (void)col; (void)uh; (void)ul;
 #else
 #if CBAS_ATTN_ABLATE & 4
-                uh.v = qh[s2]; ul.v = ql[s2];                                  // constant fragments instead of V's LDS reads
-                (void)krow; (void)col;
+                    uh.v = qh[s2]; ul.v = ql[s2];                                  // constant fragments instead of V's LDS reads
+                    (void)krow; (void)col;
 #else
-                uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
-                uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
-                ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
-                ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
+                    uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow, col)));
+                    uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + sv_off(krow + 16, col)));
+                    ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow, col)));
+                    ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + sv_off(krow + 16, col)));
 #endif
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul.v, ph[s2], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, pl[s2], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh.v, ph[s2], o[dt], 0, 0, 0);
 #endif
+                }
+            }
+            ATTN_PRIO_OFF(2);
+        };
+        for (int kb = 0; kb < nkb; ++kb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
+            __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
+            ATTN_PRIO_ON(8);
+            if (kb + 1 < nkb) stage((gb + kb + 1) & 1, pair, kb + 1);
+            else if (following < total_items) stage((gb + kb + 1) & 1, item_pair(following), 0);      // the next item's first block
+            ATTN_PRIO_OFF(8);
+            if (active) {
+                // a full block (64 real keys: every block but the last) runs without the per-tile tests, so that its four key
+                // tiles are four independent MFMA chains in one basic block; same operations per query either way
+                if (T - kb * AKB >= AKB) block(kb, std::integral_constant<bool, true>{});
+                else block(kb, std::integral_constant<bool, false>{});
             }
         }
-        ATTN_PRIO_OFF(2);
-    };
-    for (int kb = 0; kb < nkb; ++kb) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of block kb
-        __builtin_amdgcn_s_barrier();                                 // everyone's; and the other buffer is free
-        ATTN_PRIO_ON(8);
-        if (kb + 1 < nkb) stage((gb + kb + 1) & 1, pair, kb + 1);
-        else if (following < total_items) stage((gb + kb + 1) & 1, item_pair(following), 0);      // the next item's first block
-        ATTN_PRIO_OFF(8);
         if (active) {
-            // a full block (64 real keys: every block but the last) runs without the per-tile tests, so that its four key
-            // tiles are four independent MFMA chains in one basic block; same operations per query either way
-            if (T - kb * AKB >= AKB) block(kb, std::integral_constant<bool, true>{});
-            else block(kb, std::integral_constant<bool, false>{});
-        }
-    }
-    if (active) {
-    lrun = xor16_add(lrun);
-    lrun = xor32_add(lrun);
-    if (q < nq) {
-        float* row = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D;
-        const float inv = (1.0f / (ATT_VS * ATT_PS)) / lrun;          // (power of two) / l
+            lrun = xor16_add(lrun);
+            lrun = xor32_add(lrun);
+            if (q < nq) {
+                float* row = out + (q_cls ? (size_t)b : (size_t)b * T + q) * D;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const f32x4 v = (o[dt] * (1.0f / (ATT_VS * ATT_PS))) / lrun;
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f32x4 v = (o[dt] * (1.0f / (ATT_VS * ATT_PS))) / lrun;
 #if CBAS_ATTN_ABLATE & 32
-            if (v[0] == 123.456f) store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);      // never true: no stores
+                    if (v[0] == 123.456f) store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);      // never true: no stores
 #else
-            store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);
+                    store_split4(row, hd * 64 + 16 * dt + 4 * g, v, out_scale);
 #endif
-        }
-        (void)inv;
-    }
-    }                                                                  // active
-    gb += nkb;
-    item = following;                                                  // (no barrier here: the next item's first block waits + barriers as every block does)
+                }
+            }
+        }                                                                  // active
+        gb += nkb;
+        item = following;                                                  // (no barrier here: the next item's first block waits + barriers as every block does)
     }                                                                  // items
 }
 
