@@ -114,6 +114,14 @@ def build_library(force: bool = False, verbose: bool = False, debug: bool | None
     if asm_check and not debug:
         from . import asmcheck
         asmcheck.check_library(out_path, verbose=verbose)      # raises when a kernel contains the banned packed form; writes the report
+    elif asm_check:
+        # the debug variant is what the GPU suite runs beside MFMA neighbours: its debug-only objects (harness kernels) are held
+        # to the same rule; the objects it shares with the product were checked by the product's build
+        from . import asmcheck
+        rep = asmcheck.check_objects([o for o in objs if o.endswith(".debug.o")])
+        if rep["R1"]:
+            raise RuntimeError("asmcheck: debug-only kernels contain the banned packed form: " +
+                               "; ".join(f"{x['object']}: {x['kernel']}: {x['text']}" for x in rep["R1"][:8]))
     return out_path
 
 
