@@ -254,6 +254,20 @@ def _wait_done(work, give_up=None) -> None:
     work.wait()                            # completed: orders the current stream after it, returns at once
 
 
+class _SettleOnce:
+    """A transfer's host-side completion, waited for at most once however many owners ask (the session whose buffers it reads
+    asks before it is reused and when it is closed; the rank asks before it leaves).  A second ``wait()`` on a finished gloo
+    send never returns - found by the device-rows rehearsal of the RCCL ranks' control flow (tests/test_gpu_round2.py)."""
+
+    def __init__(self, work, give_up):
+        self.work, self.give_up, self.done = work, give_up, False
+
+    def __call__(self):
+        if not self.done:
+            _wait_done(self.work, self.give_up)
+            self.done = True
+
+
 class _DictStore:
     """The four store calls encode_files uses, on a dict: the world of one process has no process group store."""
 
@@ -352,6 +366,11 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     nccl = world > 1 and dist.get_backend() == "nccl"
+    # The control flow of the RCCL ranks - results left in the session's DEVICE buffers (two sessions alternating), a rank's next
+    # clip started while the previous one's sends drain, no pipelining of host copies on ranks > 0 - can be rehearsed without
+    # RCCL: CBAS_DIST_DEVICE_ROWS=1 on another backend takes the same branches and sends a host copy made at send time
+    # (tests/test_gpu_round2.py; no multi-GPU node has run the RCCL form yet).
+    devrows = nccl or (world > 1 and os.environ.get("CBAS_DIST_DEVICE_ROWS") == "1")
     paths = list(paths)
     if head is not None and (dataset_name is None or behaviors is None):
         raise ValueError("classification needs dataset_name and behaviors (infer_file's arguments)")
@@ -383,7 +402,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                     return
         hb = threading.Thread(target=heartbeat, name="cbas-heartbeat", daemon=True)
         hb.start()
-    runner = P.ClipRunner(encoder, head, temperature, sessions=2 if nccl else 1)
+    runner = P.ClipRunner(encoder, head, temperature, sessions=2 if devrows else 1)
     dev = encoder.device if nccl else torch.device("cpu")
 
     records = [{"path": p, "frames": 0, "cls_file": None, "csv_file": None, "status": "failed", "rank": None} for p in paths]
@@ -540,9 +559,10 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             if has_probs:
                 probs = res.probs if nccl else torch.from_numpy(res.probs) if not res.on_device else res.probs.cpu()
                 work += _p2p(dist.isend, probs.contiguous(), 0)
-            res.pending.extend(lambda w=w: _wait_done(w, gather_given_up) for w in work)     # before the session is reused
-            sends.append((work, rows, probs))
-            sends[:] = [s_ for s_ in sends if not all(w.is_completed() for w in s_[0])]
+            waits = [_SettleOnce(w, gather_given_up) for w in work]
+            res.pending.extend(waits)                      # before the session (whose buffers the sends read) is reused
+            sends.append((waits, rows, probs))             # ... and before this rank leaves; a transfer is waited for ONCE
+            sends[:] = [s_ for s_ in sends if not all(o.done for o in s_[0])]
         publish(clip, _ST_OK, n, has_probs)
 
     rescue_runner: list = []
@@ -556,7 +576,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
             if twin is not None:
                 if not rescue_runner:
                     rescue_runner.append(P.ClipRunner(twin, head, temperature, sessions=1))
-                deliver(clip, rescue_runner[0].run(paths[clip], None, progress_callback, device_out=nccl and rank != 0 and not lw))
+                deliver(clip, rescue_runner[0].run(paths[clip], None, progress_callback, device_out=devrows and rank != 0 and not lw))
                 return
         except Exception as e2:  # noqa: BLE001
             e = e2
@@ -567,7 +587,7 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
     # before clip i's tail - its last batches, the tail classification, the copy-out - is waited for, so the GPU never idles
     # between clips (a clip's fixed cost was ~8 ms: 10 % of a 2 048-frame clip).  On RCCL ranks > 0 the rows leave from
     # the session's device buffers instead (two sessions alternate there already).
-    pipelined = lw or not (nccl and rank != 0)
+    pipelined = lw or not (devrows and rank != 0)
     if pipelined and runner.native and len(runner._sessions) < 2:
         runner._sessions.append(None)
     prev = None                                            # (clip, pending result) of the clip before the current one
@@ -626,9 +646,9 @@ def encode_files(paths: Sequence[str], encoder, head=None, dataset_name: Optiona
                 deliver(pc, pp.result())
             except Exception as e:  # noqa: BLE001
                 failed(pc, e)
-        for work, _r, _p in sends:
-            for w in work:
-                _wait_done(w, gather_given_up)
+        for waits, _r, _p in sends:
+            for o in waits:
+                o()
         finished = True
     finally:
         if ahead is not None:                              # an error is on its way up with a clip opened ahead

@@ -406,11 +406,15 @@ def test_encode_files_cli_single_process(tmp_path, capsys):
         head.close()
 
 
-def _dist_rank(rank, world, port, td, q, backend="gloo"):
+def _dist_rank(rank, world, port, td, q, backend="gloo", device_rows=False):
     import os
     local = str(rank) if backend == "nccl" else "0"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=local,
                       LOCAL_WORLD_SIZE=str(world))
+    if device_rows:
+        os.environ["CBAS_DIST_DEVICE_ROWS"] = "1"
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=False)      # a rank still here after 100 s says where (first contact with RCCL)
     import torch.distributed as dist
     from cbas_amd import dist as cdist, pipeline as P
     from cbas_amd.head import ClassifierLSTMDeltas
@@ -431,13 +435,16 @@ def _dist_rank(rank, world, port, td, q, backend="gloo"):
     head.close()
     enc.close()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
-@pytest.mark.parametrize("backend", ["gloo"])        # the RCCL form: tests/test_zz_rccl_two_gpus.py (runs last, needs two GPUs)
-def test_encode_files_two_ranks_real_kernels(tmp_path, backend):
+@pytest.mark.parametrize("backend,device_rows", [("gloo", False), ("gloo", True)])   # the RCCL form: tests/test_zz_rccl_two_gpus.py (needs two GPUs)
+def test_encode_files_two_ranks_real_kernels(tmp_path, backend, device_rows):
     """Two processes driving the real encoder / head: rank 0's files are byte-identical to the single-process encode_file /
     infer_file results.  gloo: both ranks on the one GPU.  nccl (RCCL over xGMI, device-to-device point-to-point transfers
-    from a receiver thread): needs two GPUs - skipped on the one-GPU test box, so THIS PATH HAS NOT RUN YET."""
+    from a receiver thread): needs two GPUs - skipped on the one-GPU test box, so THIS PATH HAS NOT RUN YET.
+    device_rows (r5): the RCCL ranks' CONTROL FLOW on gloo (CBAS_DIST_DEVICE_ROWS=1: rows left in the session's device buffers,
+    two sessions alternating, the next clip started while the sends drain) - everything of that path but the transport."""
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("the RCCL path needs two GPUs")
     import hashlib, os, shutil, socket
@@ -464,7 +471,7 @@ def test_encode_files_two_ranks_real_kernels(tmp_path, backend):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, str(b), q, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, str(b), q, backend, device_rows)) for r in range(2)]
     for p in procs:
         p.start()
     try:

@@ -13,7 +13,7 @@ needs_two = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL p
 @needs_two
 def test_encode_files_two_ranks_over_rccl(tmp_path):
     from test_gpu_round2 import test_encode_files_two_ranks_real_kernels as run
-    run.__wrapped__(tmp_path, "nccl") if hasattr(run, "__wrapped__") else run(tmp_path, "nccl")
+    run.__wrapped__(tmp_path, "nccl", False) if hasattr(run, "__wrapped__") else run(tmp_path, "nccl", False)
 
 
 @needs_two
