@@ -71,6 +71,7 @@ class DinoEncoder:
         # max_batch: frames per encoder launch sequence.  A frame's row does not depend on its batch (bit-exact:
         # tests/test_gpu_parity.py::test_vitb_full_batch_invariance), so this is scheduling only: 128 runs the file path
         # ~3 % faster than 64 (fewer partly-filled tile rounds per frame; 256 adds nothing) for ~1 GB more workspace.
+        print(f"Loading DINO encoder model: {model_identifier}")          # the reference's line (backend/cbas.py:654)
         ckpt = find_checkpoint_dir(model_identifier)
         cfg, weights = load_encoder_checkpoint(ckpt)
         if precision is None:
@@ -86,6 +87,10 @@ class DinoEncoder:
                                  "interchangeable with the other modes' (pass precision=2 explicitly)")
         self._init(cfg, weights, device, max_batch, max_frame, precision)
         self.model_identifier = model_identifier
+        mode = {0: "fp16 operands - the reference's own GPU behaviour under autocast (fast mode)", 1: "fp16 activations, hi + lo split weights",
+                2: "MX-fp8 operands", 3: "fp32 end to end (label-exact)",
+                4: "fp32 with split-fp16 GEMM products (label-exact; CBAS_PRECISION=0 selects the fast mode)"}.get(int(precision), "?")
+        print(f"cbas_amd: MI355X encoder on {getattr(self, 'device', device)}, precision {int(precision)}: {mode}")
 
     @classmethod
     def from_weights(cls, cfg: ViTConfig, weights: Dict[str, np.ndarray], device="cuda", max_batch: int = 64,

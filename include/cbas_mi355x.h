@@ -72,7 +72,8 @@ typedef struct cbas_enc_config {
     int32_t max_batch;            /* frames per encoder pass (workspace size)  */
     int32_t max_height;           /* largest frame the workspace must hold     */
     int32_t max_width;
-    int32_t precision;            /* 0: fp16 operands, fp32 accumulate/residual (default; meets the 1e-3 CLS bar)
+    int32_t precision;            /* 0: fp16 operands, fp32 accumulate/residual (the fast mode; meets the 1e-3 CLS bar,
+                                        not label identity - the host mirror's default is 4, see below)
                                      1: fp16 hi+lo split weights (2 MFMA/k-step)
                                      2: MX-fp8 throughput mode (BASELINE.json configs[4]): the QKV / o_proj / up / down
                                         GEMMs take e4m3 operands with one E8M0 scale per 32 k-elements - weights packed
