@@ -125,6 +125,25 @@ def build_library(force: bool = False, verbose: bool = False, debug: bool | None
     return out_path
 
 
+def probe_library(path: str, names) -> dict:
+    """dlopen ``path`` in a CHILD process and report {"abi", "debug_build", "missing"}.  Not in this process: a library mapped
+    BEFORE torch binds to the system's libamdhip64, torch then brings its own, and with two HIP runtimes in one process the
+    first HIP call fails with "no ROCm-capable device is detected" (cbas_amd/_lib.py imports torch first for that reason).
+    Round 5's build() dlopen'ed both variants ahead of torch and a smoke() in the same process then failed on the GPU box;
+    measured afterwards: with torch imported first, even both variants in one process work."""
+    import json
+    code = ("import ctypes, json, sys\n"
+            "lib = ctypes.CDLL(sys.argv[1])\n"
+            "names = json.loads(sys.stdin.read())\n"
+            "out = {'abi': int(lib.cbas_abi_version()), 'missing': [n for n in names if not hasattr(lib, n)],\n"
+            "       'debug_build': int(lib.cbas_debug_build()) if hasattr(lib, 'cbas_debug_build') else 0}\n"
+            "print(json.dumps(out))\n")
+    r = subprocess.run([sys.executable, "-c", code, path], input=json.dumps(list(names)), capture_output=True, text=True, timeout=120)
+    if r.returncode != 0:
+        raise RuntimeError(f"could not load {path}:\n{r.stderr}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def build_all(force: bool = False, verbose: bool = False) -> list:
     return [build_library(force, verbose, debug=False), build_library(force, verbose, debug=True)]
 

@@ -71,27 +71,26 @@ def test_library_exports_every_declared_symbol():
     """include/cbas_mi355x.h <-> libcbas_mi355x.so <-> the ctypes table, without touching a GPU: the PRODUCT library exports
     exactly the declared boundary - no bring-up / harness entry point, no C++ internals (csrc/exports.map)."""
     path = B.build_library(debug=False)
-    lib = C.CDLL(path)
     declared = _declared("cbas_mi355x.h")
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    for name in declared:
-        assert hasattr(lib, name), name
+    probe = B.probe_library(path, sorted(declared))          # dlopen in a child (build.probe_library: load order against torch's HIP runtime)
+    assert not probe["missing"], probe
     exported = _exported(path)
     assert {e for e in exported if e.startswith("cbas_")} == declared, {e for e in exported if e.startswith("cbas_")} ^ declared
     assert not [e for e in exported if "debug" in e.lower()], [e for e in exported if "debug" in e.lower()]
     assert not [e for e in exported if e.startswith("_Z")], "C++ internals exported"
-    assert lib.cbas_abi_version() == _lib.EXPECTED_ABI
+    assert probe["abi"] == _lib.EXPECTED_ABI and probe["debug_build"] == 0
 
 
 def test_debug_library_is_a_superset_with_the_debug_header():
     """libcbas_mi355x_debug.so = the product boundary + include/cbas_mi355x_debug.h (what the GPU suite loads)."""
     path = B.build_library(debug=True)
-    lib = C.CDLL(path)
     product, debug = _declared("cbas_mi355x.h"), _declared("cbas_mi355x_debug.h")
+    probe = B.probe_library(path, sorted(product | debug))
     assert debug == set(_lib.DEBUG_SIGNATURES), debug ^ set(_lib.DEBUG_SIGNATURES)
     assert not (product & debug)
     assert {e for e in _exported(path) if e.startswith("cbas_")} == product | debug
-    assert lib.cbas_debug_build() == 1 and lib.cbas_abi_version() == _lib.EXPECTED_ABI
+    assert probe["debug_build"] == 1 and probe["abi"] == _lib.EXPECTED_ABI and not probe["missing"]
     assert all("debug" in d for d in debug), [d for d in debug if "debug" not in d]
 
 
