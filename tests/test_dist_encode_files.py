@@ -21,6 +21,24 @@ D, C_ = 64, 4
 NAMES = ["rest", "groom", "eat", "dig"]
 
 
+def _start_without_gpu(procs):
+    """Start the CPU ranks with no GPU visible to them: these are CPU tests (stand-in encoders, gloo), and on a GPU box every
+    child that imports torch would otherwise open the device - eight of them trip the box's limit of processes on one GPU."""
+    keys = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = os.environ["CUDA_VISIBLE_DEVICES"] = ""
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+
 class StubEncoder(DinoEncoder):
     """DinoEncoder's streaming interface (submit_host / wait, 3 slots) over a deterministic per-frame function."""
 
@@ -144,8 +162,7 @@ def test_encode_files_matches_single_process_byte_for_byte(tmp_path, world, loca
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, run_dir, q, local_writes)) for r in range(world)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     recs = q.get(timeout=180)
     for p in procs:
         p.join(120)
@@ -232,8 +249,7 @@ def _run_timed(tmp_path, world, lengths, per_frame, write_s, head_s=None, local_
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_timed_worker, args=(r, world, port, td, q, per_frame, write_s, head_s, local_writes)) for r in range(world)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     wall, recs = q.get(timeout=240)
     for p in procs:
         p.join(120)
@@ -341,8 +357,7 @@ def test_one_clip_split_over_ranks_writes_the_single_process_files(tmp_path, wor
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, run_dir, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     out, enc_only = q.get(timeout=300)
     for p in procs:
         p.join(120)
@@ -409,8 +424,7 @@ def test_split_clip_with_a_failure_on_one_rank_is_skipped_by_all_ranks_together(
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_sharded_fail_worker, args=(r, 2, port, td, q)) for r in range(2)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     got = dict(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(60)
@@ -467,8 +481,7 @@ def test_a_rank_that_leaves_early_fails_its_clips_and_rank0_returns(tmp_path):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_leaver_worker, args=(r, 2, port, td, q)) for r in range(2)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     got = {}
     for _ in range(2):
         rank, left, recs = q.get(timeout=120)
@@ -518,8 +531,7 @@ def test_receiver_does_not_wait_for_ever_for_a_lost_sender(tmp_path, mode):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_liveness_worker, args=(r, 2, port, td, q, mode)) for r in range(2)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     got = {}
     for _ in range(2 if mode == "announced_not_sent" else 1):
         rank, dt, recs = q.get(timeout=90)

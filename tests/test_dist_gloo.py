@@ -12,6 +12,24 @@ import torch.multiprocessing as mp
 from cbas_amd import dist as cdist
 
 
+def _start_without_gpu(procs):
+    """Start the CPU ranks with no GPU visible to them: these are CPU tests (stand-in encoders, gloo), and on a GPU box every
+    child that imports torch would otherwise open the device - eight of them trip the box's limit of processes on one GPU."""
+    keys = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = os.environ["CUDA_VISIBLE_DEVICES"] = ""
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -53,8 +71,7 @@ def test_two_rank_gather_gloo():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -95,8 +112,7 @@ def test_halo_exchange_gloo(world, n_frames, half):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q, n_frames, half)) for r in range(world)]
-    for p in procs:
-        p.start()
+    _start_without_gpu(procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
