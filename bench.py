@@ -780,7 +780,10 @@ def main() -> None:
                                           "bench.py itself, one batch in flight, 2 + 20 steps, frames resident "
                                           "(scripts/profile_pmc_bench.sh)"),
                                       3: ("r04_pmc_traffic_fp32.json", "gemm_f32_hbm_bytes_per_launch",
-                                          "scripts/quick_perf.py vitb16 64 3 224 3")}.get(args.precision, (None, None, None))
+                                          "scripts/quick_perf.py vitb16 64 3 224 3"),
+                                      4: ("r05_pmc_traffic_p4.json", "gemm_split_hbm_bytes_per_launch",
+                                          "bench.py --precision 4 itself, one batch in flight, 2 + 20 steps, frames resident "
+                                          "(PRECISION=4 scripts/profile_pmc_bench.sh)")}.get(args.precision, (None, None, None))
         pmc = os.path.join(HERE, "profiles", pmc_file) if pmc_file else None
         if pmc and os.path.exists(pmc) and (args.model, args.hw, B) == ("vitb16", 224, 64):
             try:

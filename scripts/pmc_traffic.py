@@ -14,10 +14,10 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    d = re.search(r"(gemm_f16_8ph_kernel|gemm_f16_kernel|attention_kernel|attention_stream_kernel|layernorm_f16_kernel|layernorm_f8_kernel)(<[^>]*>)?\(", name)
+    d = re.search(r"(gemm_f16_8ph_kernel|gemm_f16_kernel|gemm_split_pp_kernel|gemm_split_skinny_kernel|attention_kernel|attention_stream_kernel|attention_split_kernel|layernorm_f16_kernel|layernorm_f8_kernel|layernorm_f32_kernel)(<[^>]*>)?\(", name)
     if d:                                           # demangled form
         return d.group(1) + ((d.group(2) or "") if "gemm" in d.group(1) else "")
-    m = re.search(r"(\d+)(gemm_f16_8ph_kernel|gemm_f16_kernel|attention_kernel|attention_stream_kernel|layernorm_f16_kernel|layernorm_f8_kernel)(I[^v]*?E)?Ev", name)
+    m = re.search(r"(\d+)(gemm_f16_8ph_kernel|gemm_f16_kernel|gemm_split_pp_kernel|gemm_split_skinny_kernel|attention_kernel|attention_stream_kernel|attention_split_kernel|layernorm_f16_kernel|layernorm_f8_kernel|layernorm_f32_kernel)(I[^v]*?E)?Ev", name)
     if not m:
         return ""
     args = re.findall(r"Li(\d+)E", m.group(3) or "")
@@ -76,6 +76,13 @@ def main() -> None:
         "per_kernel": per,
         "gemm_f16_hbm_bytes_per_launch": int(g_b / max(1, g_n)),
     }
+    split = [k for k in per if k.startswith("gemm_split_pp")]           # precision 4's dominant kernels
+    if split:
+        s_n = sum(per[k]["launches"] for k in split)
+        s_b = sum(per[k]["launches"] * (per[k]["fetch_bytes_per_launch"] + per[k]["write_bytes_per_launch"]) for k in split)
+        doc["gemm_split_hbm_bytes_per_launch"] = int(s_b / max(1, s_n))
+        if not gemm:
+            del doc["gemm_f16_hbm_bytes_per_launch"]
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc, indent=1))
